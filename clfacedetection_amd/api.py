@@ -1,0 +1,396 @@
+"""ctypes binding of libvjhip.so — the host-side mirror of the reference's clif/clod
+interface for the detect path.
+
+The reference's public functions (clod.h:61-81, clif.h:42-73) take OpenCV/OpenCL
+types; this module keeps their names, argument order and meaning on top of the C ABI
+declared in include/vj.h, with numpy arrays standing in for IplImage / CvMat:
+
+    clodInitEnvironment(device_index)            -> Environment
+    clodInitBuffers(env, (width, height))
+    clodDetectObjects(image, cascade, env, min_window_size, max_window_size,
+                      min_neighbors, flags, use_opencl=True) -> DetectResult
+    clifIntegral(image, env)                     -> (sum, square_sum)
+    clodReleaseBuffers(env); clodReleaseEnvironment(env)
+
+There is no CPU path here: `use_opencl=False` (the reference's CPU variants) raises,
+and a missing/unbuildable libvjhip.so or a missing GPU raises VjError — nothing in this
+package falls back to the oracle or to numpy.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from dataclasses import dataclass
+
+import numpy as np
+
+from .build import LIB_PATH, build_lib
+
+VJ_MAX_STAGES = 64
+VJ_FLAG_COUNTERS = 1 << 0
+VJ_FLAG_SIGNED_MEAN = 1 << 1
+VJ_FLAG_TABLE_IN_LDS = 1 << 2
+
+# clod_flags of the reference (clod.h:17-19).  They select among the reference's CPU
+# evaluators; the HIP path has one evaluator, so they are accepted and ignored.
+CLOD_PRECOMPUTE_FEATURES = 2 << 0
+CLOD_BLOCK_IMPLEMENTATION = 2 << 1
+CLOD_PER_STAGE_ITERATIONS = 2 << 2
+
+DATA_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "data")
+
+
+class VjError(RuntimeError):
+    def __init__(self, code: int, what: str, detail: str):
+        super().__init__(f"{what}: {detail}" if detail else what)
+        self.code = code
+
+
+class CascadeInfo(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("win_w", "win_h", "n_stages", "n_trees", "n_nodes", "n_alpha",
+                                          "max_trees_per_stage", "max_nodes_per_tree", "n_tilted", "n_three_rect",
+                                          "is_stump_based", "is_stage_tree")]
+
+
+class Params(C.Structure):
+    _fields_ = [("min_w", C.c_int32), ("min_h", C.c_int32), ("max_w", C.c_int32), ("max_h", C.c_int32),
+                ("scale_factor", C.c_float), ("min_neighbors", C.c_uint32), ("flags", C.c_uint32)]
+
+
+class ScaleInfo(C.Structure):
+    _fields_ = [("scale_idx", C.c_int32), ("scale", C.c_float), ("step", C.c_float),
+                ("win_w", C.c_int32), ("win_h", C.c_int32),
+                ("equ_x", C.c_int32), ("equ_y", C.c_int32), ("equ_w", C.c_int32), ("equ_h", C.c_int32),
+                ("area", C.c_uint32), ("nx", C.c_int32), ("ny", C.c_int32), ("accepted", C.c_int32)]
+
+
+class _Image(C.Structure):
+    _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
+                ("on_device", C.c_int32)]
+
+
+class _Counters(C.Structure):
+    _fields_ = [("windows", C.c_uint64), ("stump_evals", C.c_uint64), ("gather_bytes", C.c_uint64),
+                ("stage_entered", C.c_uint64 * VJ_MAX_STAGES)]
+
+
+class _Timing(C.Structure):
+    _fields_ = [("integral_ms", C.c_float), ("cascade_ms", C.c_float), ("total_ms", C.c_float),
+                ("n_cascade_launches", C.c_int32)]
+
+
+class _Result(C.Structure):
+    _fields_ = [("rects", C.c_void_p), ("count", C.c_uint32), ("counters", _Counters), ("timing", _Timing)]
+
+
+RECT_DTYPE = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("weight", "<f4"),
+                       ("frame", "<i4"), ("scale_idx", "<i4")])
+STAGE_DTYPE = np.dtype([("first_tree", "<i4"), ("n_trees", "<i4"), ("threshold", "<f4"), ("parent", "<i4"),
+                        ("next", "<i4"), ("child", "<i4")])
+TREE_DTYPE = np.dtype([("first_node", "<i4"), ("n_nodes", "<i4"), ("first_alpha", "<i4")])
+_RECT_DESC = np.dtype([("x", "<i4"), ("y", "<i4"), ("w", "<i4"), ("h", "<i4"), ("weight", "<f4")])
+NODE_DTYPE = np.dtype([("n_rects", "<i4"), ("tilted", "<i4"), ("threshold", "<f4"), ("left", "<i4"),
+                       ("right", "<i4"), ("rect", _RECT_DESC, 3)])
+
+# every function include/vj.h declares, with its signature; tests check the library
+# exports exactly this set
+_SIGNATURES = {
+    "vj_strerror": (C.c_char_p, [C.c_int]),
+    "vj_last_error": (C.c_char_p, []),
+    "vj_cascade_load_xml": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "vj_cascade_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
+    "vj_cascade_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "vj_cascade_free": (None, [C.c_void_p]),
+    "vj_cascade_get_info": (C.c_int, [C.c_void_p, C.POINTER(CascadeInfo)]),
+    "vj_cascade_stages": (C.c_void_p, [C.c_void_p]),
+    "vj_cascade_trees": (C.c_void_p, [C.c_void_p]),
+    "vj_cascade_nodes": (C.c_void_p, [C.c_void_p]),
+    "vj_cascade_alpha": (C.c_void_p, [C.c_void_p]),
+    "vj_cascade_notice": (C.c_char_p, [C.c_void_p]),
+    "vj_params_default": (None, [C.POINTER(Params)]),
+    "vj_plan_scales": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(ScaleInfo), C.c_int,
+                                 C.POINTER(C.c_int)]),
+    "vj_plan_feature_table": (C.c_int, [C.c_void_p, C.c_int, C.POINTER(ScaleInfo), C.c_void_p, C.c_void_p]),
+    "vj_env_create": (C.c_int, [C.c_int, C.POINTER(C.c_void_p)]),
+    "vj_env_destroy": (None, [C.c_void_p]),
+    "vj_env_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
+    "vj_env_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "vj_integral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vj_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.POINTER(Params),
+                            C.POINTER(_Result)]),
+    "vj_result_free": (None, [C.POINTER(_Result)]),
+    "vj_count_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(C.c_uint64)]),
+}
+
+_lib = None
+
+
+def load_library(build: bool = True) -> C.CDLL:
+    """dlopen libvjhip.so (building it first when stale).  Raises if that fails."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = build_lib() if build else LIB_PATH
+    if not os.path.exists(path):
+        raise VjError(-1, "libvjhip.so is missing", f"expected at {path}; run clfacedetection_amd/build.py")
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)   # AttributeError here = the library does not export what vj.h declares
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int, what: str):
+    if rc != 0:
+        lib = load_library()
+        raise VjError(rc, f"{what} failed ({lib.vj_strerror(rc).decode()})", lib.vj_last_error().decode())
+
+
+def default_params(**kw) -> Params:
+    p = Params()
+    load_library().vj_params_default(C.byref(p))
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+class Cascade:
+    """CvHaarClassifierCascade stand-in (main.cpp:36 `cvLoad`)."""
+
+    def __init__(self, handle: int):
+        self._h = C.c_void_p(handle)
+        info = CascadeInfo()
+        _check(load_library().vj_cascade_get_info(self._h, C.byref(info)), "vj_cascade_get_info")
+        self.info = info
+
+    @classmethod
+    def load_xml(cls, path: str) -> "Cascade":
+        h = C.c_void_p()
+        _check(load_library().vj_cascade_load_xml(os.fsencode(path), C.byref(h)), f"vj_cascade_load_xml({path})")
+        return cls(h.value)
+
+    @classmethod
+    def load(cls, path_or_name: str) -> "Cascade":
+        """Load a .vjc file, or a stock cascade by name (e.g. 'frontalface_alt')."""
+        path = path_or_name
+        if not os.path.exists(path):
+            cand = os.path.join(DATA_DIR, f"haarcascade_{path_or_name}.vjc")
+            if os.path.exists(cand):
+                path = cand
+        if path.endswith(".xml"):
+            return cls.load_xml(path)
+        h = C.c_void_p()
+        _check(load_library().vj_cascade_load(os.fsencode(path), C.byref(h)), f"vj_cascade_load({path})")
+        return cls(h.value)
+
+    def save(self, path: str):
+        _check(load_library().vj_cascade_save(self._h, os.fsencode(path)), f"vj_cascade_save({path})")
+
+    def _view(self, fn, dtype, n):
+        ptr = fn(self._h)
+        buf = (C.c_char * (dtype.itemsize * n)).from_address(ptr)
+        return np.frombuffer(buf, dtype, n).copy()
+
+    @property
+    def stages(self): return self._view(load_library().vj_cascade_stages, STAGE_DTYPE, self.info.n_stages)
+    @property
+    def trees(self): return self._view(load_library().vj_cascade_trees, TREE_DTYPE, self.info.n_trees)
+    @property
+    def nodes(self): return self._view(load_library().vj_cascade_nodes, NODE_DTYPE, self.info.n_nodes)
+    @property
+    def alpha(self): return self._view(load_library().vj_cascade_alpha, np.dtype("<f4"), self.info.n_alpha)
+    @property
+    def notice(self) -> str: return load_library().vj_cascade_notice(self._h).decode("latin-1")
+
+    def plan_scales(self, width: int, height: int, params: Params | None = None) -> list[ScaleInfo]:
+        p = params or default_params()
+        n = C.c_int(0)
+        lib = load_library()
+        _check(lib.vj_plan_scales(self._h, width, height, C.byref(p), None, 0, C.byref(n)), "vj_plan_scales")
+        arr = (ScaleInfo * max(n.value, 1))()
+        _check(lib.vj_plan_scales(self._h, width, height, C.byref(p), arr, n.value, C.byref(n)), "vj_plan_scales")
+        return list(arr)[:n.value]
+
+    def feature_table(self, width: int, scale: ScaleInfo) -> tuple[np.ndarray, np.ndarray]:
+        off = np.zeros((self.info.n_nodes, 3, 4), np.uint32)
+        wts = np.zeros((self.info.n_nodes, 3), np.float32)
+        _check(load_library().vj_plan_feature_table(self._h, width, C.byref(scale), off.ctypes.data,
+                                                    wts.ctypes.data), "vj_plan_feature_table")
+        return off, wts
+
+    def count_windows(self, width: int, height: int, params: Params | None = None) -> int:
+        p = params or default_params()
+        out = C.c_uint64(0)
+        _check(load_library().vj_count_windows(self._h, width, height, C.byref(p), C.byref(out)), "vj_count_windows")
+        return out.value
+
+    def close(self):
+        if self._h:
+            load_library().vj_cascade_free(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class DetectResult:
+    """CLODDetectObjectsResult (clod.h:44-47) + provenance, counters and device timing."""
+    rects: np.ndarray            # RECT_DTYPE, sorted by (frame, scale_idx, y, x)
+    windows: int
+    stump_evals: int
+    gather_bytes: int
+    stage_entered: list
+    integral_ms: float
+    cascade_ms: float
+    total_ms: float
+    n_cascade_launches: int
+
+    @property
+    def match_count(self) -> int:
+        return len(self.rects)
+
+
+class Environment:
+    """CLODEnvironmentData stand-in: one HIP device, its stream and its buffers."""
+
+    def __init__(self, device_index: int = 0):
+        h = C.c_void_p()
+        _check(load_library().vj_env_create(device_index, C.byref(h)), "vj_env_create")
+        self._h = h
+
+    @property
+    def device_name(self) -> str:
+        buf = C.create_string_buffer(256)
+        _check(load_library().vj_env_device_name(self._h, buf, 256), "vj_env_device_name")
+        return buf.value.decode()
+
+    def reserve(self, width: int, height: int, batch: int = 1):
+        _check(load_library().vj_env_reserve(self._h, width, height, batch), "vj_env_reserve")
+
+    def integral(self, gray: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
+        if gray.dtype != np.uint8 or gray.ndim != 2:
+            raise ValueError("integral expects a 2-D uint8 image")
+        g = gray if gray.strides[1] == 1 else np.ascontiguousarray(gray)
+        h, w = g.shape
+        s = np.empty((h + 1, w + 1), np.uint32)
+        q = np.empty((h + 1, w + 1), np.uint64)
+        _check(load_library().vj_integral(self._h, g.ctypes.data, w, h, g.strides[0], s.ctypes.data, q.ctypes.data),
+               "vj_integral")
+        return s, q
+
+    def detect(self, cascade: Cascade, frames, params: Params | None = None) -> DetectResult:
+        """frames: 2-D uint8 array, 3-D (n, h, w) array, list of 2-D arrays, or
+        DeviceFrames (frames already resident in HBM)."""
+        p = params or default_params()
+        keep = []
+        if isinstance(frames, DeviceFrames):
+            n = frames.n
+            imgs = (_Image * max(n, 1))()
+            for i in range(n):
+                imgs[i] = _Image(frames.ptr + i * frames.stride * frames.height, frames.width, frames.height,
+                                 frames.stride, 1)
+        else:
+            if isinstance(frames, np.ndarray) and frames.ndim == 2:
+                frames = [frames]
+            frames = list(frames)
+            n = len(frames)
+            imgs = (_Image * max(n, 1))()
+            for i, f in enumerate(frames):
+                if f.dtype != np.uint8 or f.ndim != 2:
+                    raise ValueError("frames must be 2-D uint8 (8-bit single channel)")
+                g = f if f.strides[1] == 1 else np.ascontiguousarray(f)
+                keep.append(g)
+                imgs[i] = _Image(g.ctypes.data, g.shape[1], g.shape[0], g.strides[0], 0)
+        res = _Result()
+        lib = load_library()
+        _check(lib.vj_detect(self._h, cascade._h, imgs, n, C.byref(p), C.byref(res)), "vj_detect")
+        try:
+            if res.count:
+                buf = (C.c_char * (RECT_DTYPE.itemsize * res.count)).from_address(res.rects)
+                rects = np.frombuffer(buf, RECT_DTYPE, res.count).copy()
+            else:
+                rects = np.zeros(0, RECT_DTYPE)
+            k, t = res.counters, res.timing
+            return DetectResult(rects, int(k.windows), int(k.stump_evals), int(k.gather_bytes),
+                                [int(v) for v in k.stage_entered[:cascade.info.n_stages]],
+                                float(t.integral_ms), float(t.cascade_ms), float(t.total_ms),
+                                int(t.n_cascade_launches))
+        finally:
+            lib.vj_result_free(C.byref(res))
+
+    def close(self):
+        if self._h:
+            load_library().vj_env_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+@dataclass
+class DeviceFrames:
+    """A batch of equal-size 8-bit frames already resident in device memory
+    (e.g. a torch.uint8 CUDA tensor's data_ptr()); rows `stride` bytes apart,
+    frames `stride * height` bytes apart."""
+    ptr: int
+    n: int
+    height: int
+    width: int
+    stride: int
+
+    @classmethod
+    def from_torch(cls, t) -> "DeviceFrames":
+        assert t.is_cuda and t.dtype.itemsize == 1 and t.dim() == 3 and t.is_contiguous()
+        n, h, w = t.shape
+        return cls(t.data_ptr(), n, h, w, w)
+
+
+# ------------------------------------------------- reference-named entry points
+def clodInitEnvironment(device_index: int = 0) -> Environment:
+    """clod.h:61-62 / clod.cpp:72-100."""
+    return Environment(device_index)
+
+
+def clodInitBuffers(env: Environment, image_size, batch: int = 1):
+    """clod.h:67-69 / clod.cpp:102-163; image_size = (width, height) like CvSize."""
+    env.reserve(int(image_size[0]), int(image_size[1]), batch)
+
+
+def clodReleaseBuffers(env: Environment):
+    """clod.h:70-71: buffers are owned by the environment here; nothing to do."""
+
+
+def clodReleaseEnvironment(env: Environment):
+    """clod.h:64-65 / clod.cpp:173-180."""
+    env.close()
+
+
+def clifIntegral(source: np.ndarray, env: Environment, use_opencl: bool = True):
+    """clif.h:63-66 / clif.cpp:273-316: returns (sum CV_32S-as-uint32, square_sum as
+    uint64), both (h+1, w+1) — cvIntegral's layout."""
+    if not use_opencl:
+        raise VjError(4, "clifIntegral", "this package has no CPU path; the reference's CPU branch is cvIntegral")
+    return env.integral(source)
+
+
+def clodDetectObjects(image, cascade: Cascade, env: Environment, min_window_size=(0, 0), max_window_size=(0, 0),
+                      min_neighbors: int = 0, flags: int = 0, use_opencl: bool = True,
+                      vj_flags: int = 0) -> DetectResult:
+    """clod.h:72-81 / clod.cpp:1339-1356 with use_opencl=CL_TRUE → clodDetectObjectsOpenCL
+    (clod.cpp:1176-1336).  `image` may also be a batch (see Environment.detect)."""
+    if not use_opencl:
+        raise VjError(4, "clodDetectObjects", "use_opencl=False selects the reference's CPU evaluators; "
+                                              "this package implements the device path only")
+    p = default_params(min_w=int(min_window_size[0]), min_h=int(min_window_size[1]),
+                       max_w=int(max_window_size[0]), max_h=int(max_window_size[1]),
+                       min_neighbors=int(min_neighbors), flags=int(vj_flags))
+    return env.detect(cascade, image, p)

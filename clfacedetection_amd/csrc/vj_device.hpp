@@ -1,0 +1,113 @@
+// Structures shared between the host driver (vj_env.cpp) and the gfx950 kernels
+// (vj_kernels.hip).  All are plain PODs laid out for scalar (s_load) access: every
+// field a wave needs is uniform across its 64 lanes.
+#pragma once
+#include <stdint.h>
+
+namespace vj {
+
+// One accepted scale (setupScale output, clod.cpp:371-415, in device units).
+struct ScaleDev {
+    float    step;         // window stride in pixels (f32, as the reference keeps it)
+    uint32_t nx;           // windows per grid row
+    uint32_t nwin;         // nx * ny
+    uint32_t e_lt;         // equ_rect left-top, ELEMENT offset from the window origin
+    uint32_t e_dw;         // equ_rect width in elements
+    uint32_t e_dh;         // equ_rect height * stride in elements
+    float    area;         // (float)scaled_window_area
+    uint32_t table_first;  // first NodeRec of this scale in the table
+    uint32_t q_base;       // first entry of this scale's segment in the survivor queues
+    uint32_t q_cap;        // capacity of that segment (= nwin * frames in flight)
+    uint32_t scale_idx;    // k of s_k (for the detection record)
+    uint32_t pad[5];
+};
+static_assert(sizeof(ScaleDev) == 64, "ScaleDev is 64 bytes");
+
+// One cascade stage with its resolved successors (tempcv.cpp:834-861 flattened).
+struct StageDev {
+    uint32_t first_node;   // flat node index (same for every scale)
+    uint32_t n_nodes;
+    float    threshold;
+    int32_t  on_pass;      // next stage, or -1 accept
+    int32_t  on_fail;      // next stage, or -2 reject
+    uint32_t n_trees;
+    uint32_t pad[2];
+};
+static_assert(sizeof(StageDev) == 32, "StageDev is 32 bytes");
+
+// One unit of first-pass work inside a frame: a run of consecutive windows of one scale.
+struct UnitDev {
+    uint32_t scale;        // index into ScaleDev[]
+    uint32_t first;        // first window index (row-major in the scale's grid)
+    uint32_t count;        // <= UNIT_WINDOWS
+    uint32_t pad;
+};
+
+// Survivor record handed from one pass to the next: byte offset of the window origin
+// in the batch sum image (frame included) and the window's variance.  It is the
+// on-device twin of CLODSubwindowData (clod.cpp:33-38) without x/y (recoverable from
+// the offset).
+struct QEntry {
+    uint32_t off;
+    float    var;
+};
+
+// A raw detection: window origin offset + scale slot.
+struct DetEntry {
+    uint32_t off;
+    uint32_t scale;        // index into ScaleDev[]
+};
+
+constexpr int UNIT_WINDOWS = 512;   // windows per wave-unit == per-wave LDS queue capacity
+constexpr int WAVES_PER_BLOCK = 4;
+constexpr int MAX_SCALES = 128;
+
+struct CascadeArgs {
+    const uint32_t* sum;        // batch sum images, frame f at f * frame_elems
+    const uint64_t* sqsum;      // batch squared-sum images, same geometry
+    const uint32_t* table;      // NodeRec[] viewed as dwords (16 per node)
+    const ScaleDev* scales;
+    const StageDev* stages;
+    const UnitDev*  units;      // first-pass units of ONE frame
+    uint32_t n_units;           // units per frame
+    uint32_t n_frames;
+    uint32_t n_scales;
+    uint32_t frame_elems;       // elements per frame in sum / sqsum
+    uint32_t sum_bytes;         // n_frames * frame_elems * 4 (< 2^32)
+    uint32_t stride;            // elements per image row (W + 1)
+    uint32_t stage_begin, stage_end;  // stages [begin, end) evaluated by this pass
+    uint32_t total_waves;       // gridDim.x * WAVES_PER_BLOCK
+    const QEntry*   q_in;       // survivor queue read by this pass (passes > 0)
+    const uint32_t* q_in_count; // per-scale entry counts of q_in
+    QEntry*   q_out;            // survivor queue written by this pass (not the last)
+    uint32_t* q_out_count;
+    DetEntry* det;              // detections (last pass)
+    uint32_t* det_count;
+    uint32_t  det_cap;
+    uint32_t  signed_mean;      // VJ_FLAG_SIGNED_MEAN
+    unsigned long long* stage_entered;  // [VJ_MAX_STAGES] when counting, else null
+};
+
+struct IntegralArgs {
+    const uint8_t* gray;        // batch of frames
+    uint64_t gray_frame_bytes;  // distance between frames
+    uint32_t gray_stride;       // bytes per row
+    uint32_t width, height;
+    uint32_t n_frames;
+    uint32_t n_bands;           // ceil(height / BAND_ROWS)
+    uint32_t band_pitch;        // elements per band row in the band arrays (>= width, multiple of 4)
+    uint32_t* band_sum;         // [frames][bands][band_pitch]  column sums of the band / exclusive prefix
+    uint32_t* band_sq;          // [frames][bands][band_pitch]  column sums of squares of the band
+    uint64_t* band_sq_prefix;   // [frames][bands][band_pitch]  exclusive prefix of band_sq over bands
+    uint32_t* sum;              // [frames][frame_elems]
+    uint64_t* sqsum;
+    uint32_t frame_elems;
+};
+constexpr int BAND_ROWS = 8;
+
+// Launch wrappers (defined in vj_kernels.hip); stream is a hipStream_t.
+int launch_integral(const IntegralArgs& a, void* stream);
+int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool last, bool count, int n_blocks,
+                        void* stream);
+
+}  // namespace vj

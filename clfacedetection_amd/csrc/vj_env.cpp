@@ -1,0 +1,673 @@
+// Host driver of the HIP path: device buffers, per-(cascade, size, params) plans and
+// the launch sequence of one vj_detect call.  It replaces clodInitEnvironment /
+// clodInitBuffers / clodDetectObjectsOpenCL (clod.cpp:72-163, 1176-1336): where the
+// reference does, per frame, one blocking launch + count read-back per (scale, stage)
+// — up to 924 round trips at 1080p — this driver enqueues 3 integral launches and a
+// handful of cascade passes for the WHOLE batch and synchronises once.
+#include "vj_internal.hpp"
+#include "vj_device.hpp"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <tuple>
+
+namespace vj {
+
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) {                                                              \
+            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return VJ_ERR_HIP;                                                               \
+        }                                                                                    \
+    } while (0)
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return VJ_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        // grow geometrically so alternating sizes do not reallocate every call
+        size_t want = std::max(bytes, (size_t)256);
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
+            p = nullptr;
+            return e == hipErrorOutOfMemory ? VJ_ERR_NOMEM : VJ_ERR_HIP;
+        }
+        cap = want;
+        return VJ_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+// Everything that depends on (cascade, W, H, params) but not on pixel data.
+struct Plan {
+    std::vector<vj_scale_info> scales_all;   // every enumerated scale
+    std::vector<ScaleDev> scales;            // accepted scales with nwin > 0
+    std::vector<vj_scale_info> scales_info;  // same order as `scales`
+    std::vector<StageDev> stages;
+    std::vector<UnitDev> units;              // first-pass units of one frame
+    std::vector<uint32_t> pass_bounds;       // stage indices: pass p runs [b[p], b[p+1])
+    uint64_t windows_per_frame = 0;
+    uint32_t frame_elems = 0;
+    uint32_t max_reach_elems = 0;  // furthest element a window origin + feature corner touches
+    bool trees = false;
+    StageProgram prog;
+    // device copies
+    DevBuf d_table, d_scales, d_stages, d_units;
+    int frames_q = 0;  // frames the ScaleDev.q_base/q_cap currently describe
+};
+
+}  // namespace vj
+
+using namespace vj;
+
+struct vj_env {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    char name[256] = "";
+    int n_cu = 0;
+    // image buffers
+    DevBuf d_gray, d_sum, d_sqsum, d_band_sum, d_band_sq, d_band_sqp;
+    // survivor queues + counters + detections
+    DevBuf d_q[2], d_counts, d_det;
+    uint32_t det_cap = 0;
+    void* h_pinned = nullptr;  // small pinned staging for counts
+    size_t h_pinned_bytes = 0;
+    typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint32_t> PlanKey;
+    std::map<PlanKey, std::unique_ptr<Plan>> plans;
+    // tunables (env vars, read once)
+    int blocks_per_cu = 8;
+    std::vector<int> split_override;
+};
+
+namespace vj {
+
+static uint32_t f2u(float f) {
+    uint32_t u;
+    memcpy(&u, &f, 4);
+    return u;
+}
+
+static constexpr uint32_t kSlackRows = 2;  // zero rows after row H (defined reads for the
+                                           // one-column feature overshoot)
+
+static uint32_t frame_elems_for(int W, int H) {
+    uint64_t e = (uint64_t)(W + 1) * (uint64_t)(H + 1 + kSlackRows);
+    e = (e + 63u) & ~(uint64_t)63u;  // keep every frame 256-byte aligned
+    return (uint32_t)e;
+}
+
+// Default pass split: stage boundaries after which the survivor population is small
+// enough that re-packing it across the whole chip pays for the extra launch.
+static std::vector<uint32_t> default_pass_bounds(const vj_cascade& c, const StageProgram& prog,
+                                                 const std::vector<int>& override_) {
+    const uint32_t n = (uint32_t)c.stages.size();
+    std::vector<uint32_t> b{0};
+    if (!override_.empty()) {
+        for (int v : override_)
+            if (v > (int)b.back() && v < (int)n) b.push_back((uint32_t)v);
+    } else {
+        // cut after roughly 80, 320 and 1000 cumulative nodes (frontalface_alt: 4 | 9 | 15)
+        const uint32_t cuts[3] = {80, 330, 1000};
+        uint32_t acc = 0;
+        int ci = 0;
+        for (uint32_t s = 0; s < n && ci < 3; ++s) {
+            acc += prog.n_nodes[s];
+            if (acc >= cuts[ci] && s + 1 < n) {
+                b.push_back(s + 1);
+                ++ci;
+            }
+        }
+    }
+    b.push_back(n);
+    return b;
+}
+
+static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_params& p, Plan* pl) {
+    if ((int)c.stages.size() > VJ_MAX_STAGES) {
+        set_error("cascade has %zu stages; at most %d are supported", c.stages.size(), VJ_MAX_STAGES);
+        return VJ_ERR_LIMIT;
+    }
+    pl->prog = build_stage_program(c);
+    for (const auto& t : c.trees)
+        if (t.n_nodes != 1) pl->trees = true;
+    for (size_t s = 0; s < c.stages.size(); ++s) {
+        const bool linear = pl->prog.on_fail[s] == STAGE_REJECT &&
+                            (pl->prog.on_pass[s] == (int)s + 1 ||
+                             (pl->prog.on_pass[s] == STAGE_ACCEPT && s + 1 == c.stages.size()));
+        if (!linear) {
+            set_error("stage-tree cascades (stage %zu has a sibling branch) are not supported yet", s);
+            return VJ_ERR_UNSUPPORTED;
+        }
+    }
+    pl->scales_all = plan_scales(c, W, H, p);
+    pl->frame_elems = frame_elems_for(W, H);
+    const uint32_t stride = (uint32_t)W + 1u;
+    const size_t n_nodes = c.nodes.size();
+
+    std::vector<NodeRec> table;
+    for (const vj_scale_info& si : pl->scales_all) {
+        if (!si.accepted || si.nx <= 0 || si.ny <= 0) continue;
+        if (pl->scales.size() >= (size_t)MAX_SCALES) {
+            set_error("more than %d scales", MAX_SCALES);
+            return VJ_ERR_LIMIT;
+        }
+        ScaleDev sd;
+        memset(&sd, 0, sizeof(sd));
+        sd.step = si.step;
+        sd.nx = (uint32_t)si.nx;
+        sd.nwin = (uint32_t)si.nx * (uint32_t)si.ny;
+        sd.e_lt = (uint32_t)si.equ_y * stride + (uint32_t)si.equ_x;
+        sd.e_dw = (uint32_t)si.equ_w;
+        sd.e_dh = (uint32_t)si.equ_h * stride;
+        sd.area = (float)si.area;
+        sd.table_first = (uint32_t)table.size();
+        sd.scale_idx = (uint32_t)si.scale_idx;
+        table.resize(table.size() + n_nodes);
+        int rc = build_node_table(c, W, si, table.data() + sd.table_first);
+        if (rc) return rc;
+        // furthest element any gather of this scale can touch, relative to frame start
+        const uint32_t x_max = (uint32_t)std::lrint((double)((float)(si.nx - 1) * si.step));
+        const uint32_t y_max = (uint32_t)std::lrint((double)((float)(si.ny - 1) * si.step));
+        uint32_t reach = sd.e_lt + sd.e_dh + sd.e_dw;
+        for (size_t k = 0; k < n_nodes; ++k) {
+            const NodeRec& r = table[sd.table_first + k];
+            const uint32_t dw[3] = {r.dw01 & 0xffffu, r.dw01 >> 16, r.dw2_flags & 0xffffu};
+            for (int q = 0; q < 3; ++q)
+                if (q < 2 || r.w[2] != 0.0f) reach = std::max(reach, (r.lt[q] + r.dh[q] + dw[q]) / 4u);
+        }
+        reach += y_max * stride + x_max;
+        pl->max_reach_elems = std::max(pl->max_reach_elems, reach);
+        pl->windows_per_frame += sd.nwin;
+        // first-pass units: runs of UNIT_WINDOWS consecutive windows
+        const uint32_t slot = (uint32_t)pl->scales.size();
+        for (uint32_t f = 0; f < sd.nwin; f += UNIT_WINDOWS)
+            pl->units.push_back(UnitDev{slot, f, std::min<uint32_t>(UNIT_WINDOWS, sd.nwin - f), 0});
+        pl->scales.push_back(sd);
+        pl->scales_info.push_back(si);
+    }
+    if (pl->max_reach_elems >= pl->frame_elems) {
+        set_error("feature reach %u exceeds the frame allocation %u", pl->max_reach_elems, pl->frame_elems);
+        return VJ_ERR_LIMIT;
+    }
+    for (size_t s = 0; s < c.stages.size(); ++s) {
+        StageDev sd;
+        memset(&sd, 0, sizeof(sd));
+        sd.first_node = pl->prog.first_node[s];
+        sd.n_nodes = pl->prog.n_nodes[s];
+        sd.threshold = c.stages[s].threshold;
+        sd.on_pass = pl->prog.on_pass[s];
+        sd.on_fail = pl->prog.on_fail[s];
+        sd.n_trees = (uint32_t)c.stages[s].n_trees;
+        pl->stages.push_back(sd);
+    }
+    pl->pass_bounds = default_pass_bounds(c, pl->prog, e->split_override);
+
+    int rc;
+    if ((rc = pl->d_table.ensure(std::max<size_t>(table.size(), 1) * sizeof(NodeRec)))) return rc;
+    if ((rc = pl->d_scales.ensure(std::max<size_t>(pl->scales.size(), 1) * sizeof(ScaleDev)))) return rc;
+    if ((rc = pl->d_stages.ensure(pl->stages.size() * sizeof(StageDev)))) return rc;
+    if ((rc = pl->d_units.ensure(std::max<size_t>(pl->units.size(), 1) * sizeof(UnitDev)))) return rc;
+    if (!table.empty())
+        HIP_TRY(hipMemcpy(pl->d_table.p, table.data(), table.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pl->d_stages.p, pl->stages.data(), pl->stages.size() * sizeof(StageDev), hipMemcpyHostToDevice));
+    if (!pl->units.empty())
+        HIP_TRY(hipMemcpy(pl->d_units.p, pl->units.data(), pl->units.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
+    return VJ_OK;
+}
+
+// (Re)lay out the per-scale queue segments for `frames` frames in flight.
+static int layout_queues(Plan* pl, int frames, uint64_t* total_entries) {
+    uint64_t base = 0;
+    for (ScaleDev& sd : pl->scales) {
+        sd.q_base = (uint32_t)base;
+        sd.q_cap = sd.nwin * (uint32_t)frames;
+        base += (uint64_t)sd.nwin * (uint64_t)frames;
+    }
+    *total_entries = base;
+    if (base > 0xffffffffull) {
+        set_error("survivor queue needs %llu entries", (unsigned long long)base);
+        return VJ_ERR_LIMIT;
+    }
+    if (pl->frames_q != frames && !pl->scales.empty()) {
+        HIP_TRY(hipMemcpy(pl->d_scales.p, pl->scales.data(), pl->scales.size() * sizeof(ScaleDev),
+                          hipMemcpyHostToDevice));
+        pl->frames_q = frames;
+    }
+    return VJ_OK;
+}
+
+static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, Plan** out) {
+    vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), 0u);
+    auto it = e->plans.find(key);
+    if (it != e->plans.end()) {
+        *out = it->second.get();
+        return VJ_OK;
+    }
+    auto pl = std::make_unique<Plan>();
+    int rc = build_plan(e, *c, W, H, p, pl.get());
+    if (rc) {
+        pl->d_table.release();
+        pl->d_scales.release();
+        pl->d_stages.release();
+        pl->d_units.release();
+        return rc;
+    }
+    *out = pl.get();
+    e->plans[key] = std::move(pl);
+    return VJ_OK;
+}
+
+static int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_gray) {
+    const size_t fe = frame_elems_for(W, H);
+    const uint32_t n_bands = ((uint32_t)H + BAND_ROWS - 1) / BAND_ROWS;
+    const uint32_t band_pitch = ((uint32_t)W + 3u) & ~3u;
+    int rc;
+    const size_t sum_bytes = fe * 4 * (size_t)frames, sq_bytes = fe * 8 * (size_t)frames;
+    const bool grow = sum_bytes > e->d_sum.cap || sq_bytes > e->d_sqsum.cap;
+    if ((rc = e->d_sum.ensure(sum_bytes))) return rc;
+    if ((rc = e->d_sqsum.ensure(sq_bytes))) return rc;
+    (void)grow;
+    if (need_gray) {
+        const size_t gstride = ((size_t)W + 3) & ~(size_t)3;
+        if ((rc = e->d_gray.ensure(gstride * (size_t)H * (size_t)frames))) return rc;
+    }
+    const size_t band_elems = (size_t)frames * n_bands * band_pitch;
+    if ((rc = e->d_band_sum.ensure(band_elems * 4))) return rc;
+    if ((rc = e->d_band_sq.ensure(band_elems * 4))) return rc;
+    if ((rc = e->d_band_sqp.ensure(band_elems * 8))) return rc;
+    return VJ_OK;
+}
+
+// Enqueue the three integral kernels for `frames` frames already on the device.
+static int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int stride, int W, int H, int frames) {
+    IntegralArgs ia;
+    memset(&ia, 0, sizeof(ia));
+    ia.gray = d_gray;
+    ia.gray_frame_bytes = frame_bytes;
+    ia.gray_stride = (uint32_t)stride;
+    ia.width = (uint32_t)W;
+    ia.height = (uint32_t)H;
+    ia.n_frames = (uint32_t)frames;
+    ia.n_bands = ((uint32_t)H + BAND_ROWS - 1) / BAND_ROWS;
+    ia.band_pitch = ((uint32_t)W + 3u) & ~3u;
+    ia.band_sum = (uint32_t*)e->d_band_sum.p;
+    ia.band_sq = (uint32_t*)e->d_band_sq.p;
+    ia.band_sq_prefix = (uint64_t*)e->d_band_sqp.p;
+    ia.sum = (uint32_t*)e->d_sum.p;
+    ia.sqsum = (uint64_t*)e->d_sqsum.p;
+    ia.frame_elems = frame_elems_for(W, H);
+    // the slack rows after row H (and the alignment tail) must read as zero
+    const size_t used = (size_t)(W + 1) * (size_t)(H + 1);
+    for (int f = 0; f < frames; ++f) {
+        HIP_TRY(hipMemsetAsync((uint32_t*)e->d_sum.p + (size_t)f * ia.frame_elems + used, 0,
+                               (ia.frame_elems - used) * 4, e->stream));
+        HIP_TRY(hipMemsetAsync((uint64_t*)e->d_sqsum.p + (size_t)f * ia.frame_elems + used, 0,
+                               (ia.frame_elems - used) * 8, e->stream));
+    }
+    int hrc = launch_integral(ia, e->stream);
+    if (hrc) {
+        set_error("integral launch failed: %s", hipGetErrorString((hipError_t)hrc));
+        return VJ_ERR_HIP;
+    }
+    return VJ_OK;
+}
+
+// Upload host frames (or gather strided device frames) into d_gray with a 4-byte
+// aligned pitch.  Returns the device pointer / pitch the integral kernels should use.
+static int stage_frames(vj_env* e, const vj_image* frames, int n, int W, int H, const uint8_t** d_ptr,
+                        size_t* frame_bytes, int* stride) {
+    bool all_dev = true, contiguous = true;
+    for (int i = 0; i < n; ++i) {
+        if (!frames[i].on_device) all_dev = false;
+        if (i > 0 && (frames[i].stride != frames[0].stride ||
+                      frames[i].data != frames[0].data + (size_t)i * (size_t)frames[0].stride * (size_t)H))
+            contiguous = false;
+    }
+    if (all_dev && contiguous) {  // use the caller's device batch in place
+        *d_ptr = frames[0].data;
+        *stride = frames[0].stride;
+        *frame_bytes = (size_t)frames[0].stride * (size_t)H;
+        return VJ_OK;
+    }
+    const size_t gstride = ((size_t)W + 3) & ~(size_t)3;
+    for (int i = 0; i < n; ++i) {
+        uint8_t* dst = (uint8_t*)e->d_gray.p + (size_t)i * gstride * (size_t)H;
+        HIP_TRY(hipMemcpy2DAsync(dst, gstride, frames[i].data, (size_t)frames[i].stride, (size_t)W, (size_t)H,
+                                 frames[i].on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+    }
+    *d_ptr = (const uint8_t*)e->d_gray.p;
+    *stride = (int)gstride;
+    *frame_bytes = gstride * (size_t)H;
+    return VJ_OK;
+}
+
+struct RawDet {
+    int frame;
+    uint32_t slot, x, y;
+};
+
+// One sub-batch: frames [f0, f0+nf).  Appends decoded detections to `dets`.
+static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, int nf, int W, int H,
+                           const vj_params& p, std::vector<RawDet>* dets, vj_counters* ctr, vj_timing* tm) {
+    int rc;
+    bool need_gray = false;
+    for (int i = 0; i < nf; ++i)
+        if (!frames[f0 + i].on_device) need_gray = true;
+    // strided / scattered device frames are gathered too
+    need_gray = true;
+    if ((rc = ensure_image_buffers(e, W, H, nf, need_gray))) return rc;
+    uint64_t q_entries = 0;
+    if ((rc = layout_queues(pl, nf, &q_entries))) return rc;
+    const size_t n_pass = pl->pass_bounds.size() - 1;
+    if (n_pass > 1) {
+        if ((rc = e->d_q[0].ensure(std::max<uint64_t>(q_entries, 1) * sizeof(QEntry)))) return rc;
+        if (n_pass > 2 && (rc = e->d_q[1].ensure(std::max<uint64_t>(q_entries, 1) * sizeof(QEntry)))) return rc;
+    }
+    // counters block: [2][MAX_SCALES] queue counts | det_count | pad | stage_entered[VJ_MAX_STAGES] (u64)
+    const size_t counts_bytes = (2 * MAX_SCALES + 2) * sizeof(uint32_t) + VJ_MAX_STAGES * sizeof(uint64_t);
+    if ((rc = e->d_counts.ensure(counts_bytes))) return rc;
+    if (e->det_cap == 0) {
+        e->det_cap = 1u << 16;
+        if ((rc = e->d_det.ensure((size_t)e->det_cap * sizeof(DetEntry)))) return rc;
+    }
+    uint32_t* d_qcount[2] = {(uint32_t*)e->d_counts.p, (uint32_t*)e->d_counts.p + MAX_SCALES};
+    uint32_t* d_det_count = (uint32_t*)e->d_counts.p + 2 * MAX_SCALES;
+    unsigned long long* d_stage_entered = (unsigned long long*)((uint32_t*)e->d_counts.p + 2 * MAX_SCALES + 2);
+
+    const uint8_t* d_gray;
+    size_t gray_frame_bytes;
+    int gray_stride;
+    if ((rc = stage_frames(e, frames + f0, nf, W, H, &d_gray, &gray_frame_bytes, &gray_stride))) return rc;
+
+    HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+    if ((rc = enqueue_integral(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf))) return rc;
+    HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+
+    const bool count = (p.flags & VJ_FLAG_COUNTERS) != 0;
+    const int n_blocks = std::max(1, e->n_cu * e->blocks_per_cu);
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        HIP_TRY(hipMemsetAsync(e->d_counts.p, 0, counts_bytes, e->stream));
+        HIP_TRY(hipEventRecord(e->ev[2], e->stream));
+        CascadeArgs ca;
+        memset(&ca, 0, sizeof(ca));
+        ca.sum = (const uint32_t*)e->d_sum.p;
+        ca.sqsum = (const uint64_t*)e->d_sqsum.p;
+        ca.table = (const uint32_t*)pl->d_table.p;
+        ca.scales = (const ScaleDev*)pl->d_scales.p;
+        ca.stages = (const StageDev*)pl->d_stages.p;
+        ca.units = (const UnitDev*)pl->d_units.p;
+        ca.n_units = (uint32_t)pl->units.size();
+        ca.n_frames = (uint32_t)nf;
+        ca.n_scales = (uint32_t)pl->scales.size();
+        ca.frame_elems = pl->frame_elems;
+        ca.sum_bytes = (uint32_t)((uint64_t)pl->frame_elems * 4u * (uint64_t)nf);
+        ca.stride = (uint32_t)W + 1u;
+        ca.total_waves = (uint32_t)n_blocks * WAVES_PER_BLOCK;
+        ca.det = (DetEntry*)e->d_det.p;
+        ca.det_count = d_det_count;
+        ca.det_cap = e->det_cap;
+        ca.signed_mean = (p.flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
+        ca.stage_entered = d_stage_entered;
+        int launches = 0;
+        if (ca.n_units > 0) {
+            for (size_t ps = 0; ps < n_pass; ++ps) {
+                ca.stage_begin = pl->pass_bounds[ps];
+                ca.stage_end = pl->pass_bounds[ps + 1];
+                const bool last = ps + 1 == n_pass;
+                const int in = (int)((ps + 1) & 1), outq = (int)(ps & 1);  // pass 0 writes q[0], pass 1 reads q[0] writes q[1] ...
+                ca.q_in = (const QEntry*)e->d_q[in].p;
+                ca.q_in_count = d_qcount[in];
+                ca.q_out = (QEntry*)e->d_q[outq].p;
+                ca.q_out_count = d_qcount[outq];
+                if (ps >= 2)  // the out-queue of pass ps was the in-queue of pass ps-1: reset its counts
+                    HIP_TRY(hipMemsetAsync(d_qcount[outq], 0, MAX_SCALES * sizeof(uint32_t), e->stream));
+                int hrc = launch_cascade_pass(ca, ps == 0, pl->trees, last, count, n_blocks, e->stream);
+                if (hrc) {
+                    set_error("cascade launch failed: %s", hipGetErrorString((hipError_t)hrc));
+                    return VJ_ERR_HIP;
+                }
+                ++launches;
+            }
+        }
+        HIP_TRY(hipEventRecord(e->ev[3], e->stream));
+        // read back the counters block
+        HIP_TRY(hipMemcpyAsync(e->h_pinned, e->d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        const uint32_t n_det = ((const uint32_t*)e->h_pinned)[2 * MAX_SCALES];
+        float ms_i = 0, ms_c = 0, ms_t = 0;
+        HIP_TRY(hipEventElapsedTime(&ms_i, e->ev[0], e->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms_c, e->ev[2], e->ev[3]));
+        HIP_TRY(hipEventElapsedTime(&ms_t, e->ev[0], e->ev[3]));
+        if (n_det > e->det_cap) {  // detections overflowed: grow and redo the cascade passes
+            uint32_t want = e->det_cap;
+            while (want < n_det) want *= 2;
+            if ((rc = e->d_det.ensure((size_t)want * sizeof(DetEntry)))) return rc;
+            e->det_cap = want;
+            continue;
+        }
+        if (attempt == 0) tm->integral_ms += ms_i;
+        tm->cascade_ms += ms_c;
+        tm->total_ms += ms_t;
+        tm->n_cascade_launches += launches;
+        if (count) {
+            const unsigned long long* se =
+                (const unsigned long long*)((const uint32_t*)e->h_pinned + 2 * MAX_SCALES + 2);
+            for (size_t s = 0; s < pl->stages.size(); ++s) ctr->stage_entered[s] += se[s];
+        }
+        std::vector<DetEntry> raw(n_det);
+        if (n_det) HIP_TRY(hipMemcpy(raw.data(), e->d_det.p, (size_t)n_det * sizeof(DetEntry), hipMemcpyDeviceToHost));
+        const uint32_t stride = (uint32_t)W + 1u;
+        const uint64_t fbytes = (uint64_t)pl->frame_elems * 4u;
+        for (const DetEntry& d : raw) {
+            const uint32_t f = (uint32_t)(d.off / fbytes);
+            const uint32_t el = (uint32_t)((d.off - (uint64_t)f * fbytes) / 4u);
+            dets->push_back(RawDet{f0 + (int)f, d.scale, el % stride, el / stride});
+        }
+        return VJ_OK;
+    }
+    set_error("detection buffer overflow persisted");
+    return VJ_ERR_LIMIT;
+}
+
+}  // namespace vj
+
+extern "C" {
+
+int vj_env_create(int device_index, vj_env** out) {
+    if (!out) return VJ_ERR_ARG;
+    *out = nullptr;
+    int n = 0;
+    hipError_t he = hipGetDeviceCount(&n);
+    if (he != hipSuccess || n <= 0) {
+        set_error("no HIP device (hipGetDeviceCount: %s); this library has no CPU fallback",
+                  he == hipSuccess ? "0 devices" : hipGetErrorString(he));
+        return VJ_ERR_NO_DEVICE;
+    }
+    if (device_index < 0 || device_index >= n) {
+        set_error("device_index %d out of range [0,%d)", device_index, n);
+        return VJ_ERR_ARG;
+    }
+    auto e = std::make_unique<vj_env>();
+    e->device = device_index;
+    HIP_TRY(hipSetDevice(device_index));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, device_index));
+    snprintf(e->name, sizeof(e->name), "%s (%s)", prop.name, prop.gcnArchName);
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+        set_error("device %d is %s; the kernels are built for gfx950 only", device_index, prop.gcnArchName);
+        return VJ_ERR_NO_DEVICE;
+    }
+    e->n_cu = prop.multiProcessorCount;
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
+    for (auto& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+    e->h_pinned_bytes = 4096;
+    HIP_TRY(hipHostMalloc(&e->h_pinned, e->h_pinned_bytes, hipHostMallocDefault));
+    if (const char* s = getenv("VJ_BLOCKS_PER_CU")) e->blocks_per_cu = std::max(1, atoi(s));
+    if (const char* s = getenv("VJ_PASS_SPLIT")) {  // e.g. "4,9,15"
+        for (const char* q = s; *q;) {
+            char* endp;
+            long v = strtol(q, &endp, 10);
+            if (endp == q) break;
+            e->split_override.push_back((int)v);
+            q = *endp ? endp + 1 : endp;
+        }
+    }
+    *out = e.release();
+    return VJ_OK;
+}
+
+void vj_env_destroy(vj_env* e) {
+    if (!e) return;
+    (void)hipSetDevice(e->device);
+    if (e->stream) (void)hipStreamSynchronize(e->stream);
+    for (auto& kv : e->plans) {
+        kv.second->d_table.release();
+        kv.second->d_scales.release();
+        kv.second->d_stages.release();
+        kv.second->d_units.release();
+    }
+    for (DevBuf* b : {&e->d_gray, &e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_q[0],
+                      &e->d_q[1], &e->d_counts, &e->d_det})
+        b->release();
+    if (e->h_pinned) (void)hipHostFree(e->h_pinned);
+    for (auto& ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    if (e->stream) (void)hipStreamDestroy(e->stream);
+    delete e;
+}
+
+int vj_env_device_name(const vj_env* e, char* buf, size_t cap) {
+    if (!e || !buf || cap == 0) return VJ_ERR_ARG;
+    snprintf(buf, cap, "%s, %d CUs", e->name, e->n_cu);
+    return VJ_OK;
+}
+
+int vj_env_reserve(vj_env* e, int max_w, int max_h, int max_batch) {
+    if (!e || max_w <= 0 || max_h <= 0 || max_batch <= 0) return VJ_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    return ensure_image_buffers(e, max_w, max_h, max_batch, true);
+}
+
+int vj_integral(vj_env* e, const uint8_t* gray, int w, int h, int stride, uint32_t* sum, uint64_t* sqsum) {
+    if (!e || !gray || !sum || !sqsum || w <= 0 || h <= 0 || stride < w) return VJ_ERR_ARG;
+    if ((uint64_t)(w + 1) * (uint64_t)(h + 3) >= (1ull << 30)) {
+        set_error("image too large");
+        return VJ_ERR_LIMIT;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    int rc;
+    if ((rc = ensure_image_buffers(e, w, h, 1, true))) return rc;
+    vj_image im{gray, w, h, stride, 0};
+    const uint8_t* d_gray;
+    size_t fb;
+    int gs;
+    if ((rc = stage_frames(e, &im, 1, w, h, &d_gray, &fb, &gs))) return rc;
+    if ((rc = enqueue_integral(e, d_gray, fb, gs, w, h, 1))) return rc;
+    const size_t n = (size_t)(w + 1) * (size_t)(h + 1);
+    HIP_TRY(hipMemcpyAsync(sum, e->d_sum.p, n * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipMemcpyAsync(sqsum, e->d_sqsum.p, n * 8, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return VJ_OK;
+}
+
+int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames, const vj_params* p,
+              vj_result* out) {
+    if (!e || !c || !p || !out || n_frames < 0 || (n_frames > 0 && !frames)) return VJ_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    if (n_frames == 0) return VJ_OK;
+    if (!(p->scale_factor > 1.0f)) {
+        set_error("scale_factor must be > 1");
+        return VJ_ERR_ARG;
+    }
+    if (p->min_neighbors != 0) {
+        set_error("min_neighbors != 0 (grouping) is not part of the raw-candidate contract yet");
+        return VJ_ERR_UNSUPPORTED;
+    }
+    const int W = frames[0].width, H = frames[0].height;
+    if (W <= 0 || H <= 0) return VJ_ERR_ARG;
+    for (int i = 0; i < n_frames; ++i) {
+        if (!frames[i].data || frames[i].width != W || frames[i].height != H || frames[i].stride < W) {
+            set_error("frame %d: all frames of a batch must be non-null and of equal size", i);
+            return VJ_ERR_ARG;
+        }
+    }
+    if ((uint64_t)(W + 1) * (uint64_t)(H + 3) >= (1ull << 30)) {
+        set_error("image too large");
+        return VJ_ERR_LIMIT;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    Plan* pl;
+    int rc = get_plan(e, c, W, H, *p, &pl);
+    if (rc) return rc;
+
+    // Sub-batch so that 32-bit byte offsets into the batch sum image never wrap and the
+    // worst-case survivor queues stay within a fixed budget.
+    const uint64_t frame_bytes = (uint64_t)pl->frame_elems * 4u;
+    uint64_t max_frames = (0xffffffffull - (uint64_t)pl->max_reach_elems * 4u - 16u) / frame_bytes;
+    const uint64_t q_budget = 6ull << 30;  // bytes per queue
+    if (pl->windows_per_frame)
+        max_frames = std::min<uint64_t>(max_frames, std::max<uint64_t>(1, q_budget / (pl->windows_per_frame * sizeof(QEntry))));
+    max_frames = std::min<uint64_t>(max_frames, std::max<uint64_t>(1, 0xffffffffull / std::max<uint64_t>(1, pl->windows_per_frame)));
+    if (max_frames == 0) {
+        set_error("a single frame exceeds the 32-bit offset range");
+        return VJ_ERR_LIMIT;
+    }
+    std::vector<RawDet> dets;
+    for (int f0 = 0; f0 < n_frames; f0 += (int)max_frames) {
+        const int nf = (int)std::min<uint64_t>(max_frames, (uint64_t)(n_frames - f0));
+        rc = detect_subbatch(e, pl, frames, f0, nf, W, H, *p, &dets, &out->counters, &out->timing);
+        if (rc) return rc;
+    }
+    // deterministic order: (frame, scale_idx, y, x)
+    std::sort(dets.begin(), dets.end(), [](const RawDet& a, const RawDet& b) {
+        return std::tie(a.frame, a.slot, a.y, a.x) < std::tie(b.frame, b.slot, b.y, b.x);
+    });
+    out->count = (uint32_t)dets.size();
+    if (!dets.empty()) {
+        out->rects = (vj_rect*)malloc(dets.size() * sizeof(vj_rect));
+        if (!out->rects) return VJ_ERR_NOMEM;
+        for (size_t i = 0; i < dets.size(); ++i) {
+            const vj_scale_info& si = pl->scales_info[dets[i].slot];
+            out->rects[i] = vj_rect{(int32_t)dets[i].x, (int32_t)dets[i].y, si.win_w, si.win_h, 0.0f, dets[i].frame,
+                                    si.scale_idx};
+        }
+    }
+    if (p->flags & VJ_FLAG_COUNTERS) {
+        vj_counters& k = out->counters;
+        k.windows = pl->windows_per_frame * (uint64_t)n_frames;
+        uint64_t rect_evals = 0;
+        for (size_t s = 0; s < pl->stages.size(); ++s) {
+            // exact for stump cascades; for multi-node trees this is the upper bound
+            // (every node of every tree) — see DESIGN.md
+            k.stump_evals += k.stage_entered[s] * pl->prog.n_nodes[s];
+            rect_evals += k.stage_entered[s] * pl->prog.n_rects[s];
+        }
+        k.gather_bytes = 48ull * k.windows + 16ull * rect_evals;
+    }
+    return VJ_OK;
+}
+
+void vj_result_free(vj_result* r) {
+    if (!r) return;
+    free(r->rects);
+    r->rects = nullptr;
+    r->count = 0;
+}
+
+}  // extern "C"

@@ -1,0 +1,465 @@
+// gfx950 (CDNA4, wave64) kernels of the Viola–Jones detect path.
+//
+//  * integral + squared-integral image  (what cvIntegral computes for the reference,
+//    clif.cpp:280-285, 326-335; the reference's own integral kernels clif.cl:79-120
+//    are unused by detect and wrong — SURVEY.md §2.1)
+//  * the cascade evaluator, replacing runStage (clod.cl:32-93) and its host driver
+//    loop (clod.cpp:1212-1322): one window per lane, per-wave survivor queue in LDS
+//    compacted with __ballot after every stage, node records fetched through the
+//    scalar cache (they are uniform across the wave), a few launches per batch
+//    instead of one launch + host round trip per (scale, stage).
+//
+// Arithmetic contract: IEEE binary32, no contraction, operations in
+// the reference's order.  This file MUST be compiled with -ffp-contract=off; HIP's
+// default correctly-rounded f32 divide/sqrt is relied upon.
+#include <hip/hip_runtime.h>
+#include "vj_device.hpp"
+
+namespace vj {
+
+// Read-only, wave-uniform data goes through address space 4 so that the compiler may
+// use s_load (scalar cache) even though the kernel also stores to global memory.
+template <typename T>
+using kptr = const T __attribute__((address_space(4)))*;
+template <typename T>
+__device__ __forceinline__ kptr<T> as_k(const T* p) {
+    return (kptr<T>)(uintptr_t)p;
+}
+
+__device__ __forceinline__ uint32_t lane_id() { return threadIdx.x & 63u; }
+
+// Number of set bits of `mask` below this lane.
+__device__ __forceinline__ uint32_t mbcnt(unsigned long long mask) {
+    return __builtin_amdgcn_mbcnt_hi((uint32_t)(mask >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mask, 0u));
+}
+
+// Image gathers go through buffer loads: the 128-bit resource descriptor and the
+// scalar offset (a rectangle corner, uniform across the wave) live in SGPRs and the
+// lane contributes only its 32-bit window offset, so a gather costs no VALU address
+// arithmetic at all:  buffer_load_dword v, v_off, s[rsrc], s_corner offen.
+// Out-of-range offsets return 0 instead of faulting.
+using rsrc_t = __amdgpu_buffer_rsrc_t;
+__device__ __forceinline__ rsrc_t make_rsrc(const void* base, uint32_t bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, bytes, 0x00020000);
+}
+__device__ __forceinline__ uint32_t ld_u32(rsrc_t r, uint32_t lane_off, uint32_t uniform_off) {
+    return __builtin_amdgcn_raw_buffer_load_b32(r, lane_off, uniform_off, 0);
+}
+__device__ __forceinline__ uint64_t ld_u64(rsrc_t r, uint32_t lane_off, uint32_t uniform_off) {
+    const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, uniform_off, 0);
+    return (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+}
+
+// 64-byte node record as the scalar unit loads it (one s_load_dwordx16).
+typedef uint32_t NodeRecDev __attribute__((ext_vector_type(16)));
+
+// ===================================================================== integral
+// Three launches per batch:
+//   1. band_colsum : per 8-row band, per column: sum and sum of squares (reads u8 once)
+//   2. band_scan   : per column, exclusive prefix of those over the bands
+//   3. band_rows   : one wave per band; per row: running column totals -> wave prefix
+//                    scan along x (__shfl_up) -> + carry of the chunks to the left.
+// All integers, so the result is exact: sum wraps mod 2^32 like CV_32S, sqsum is u64.
+
+__device__ __forceinline__ uint32_t load_px4(const uint8_t* row, uint32_t x, uint32_t width) {
+    // four pixels x..x+3 packed little-endian; pixels beyond the row read as 0
+    const uint8_t* p = row + x;
+    if (x + 4 <= width && ((uintptr_t)p & 3u) == 0) return *reinterpret_cast<const uint32_t*>(p);
+    uint32_t v = 0;
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (x + c < width) v |= (uint32_t)p[c] << (8 * c);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void band_colsum(IntegralArgs a) {
+    const uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    const uint32_t band = blockIdx.y, frame = blockIdx.z;
+    if (x >= a.band_pitch) return;
+    const uint8_t* img = a.gray + (size_t)frame * a.gray_frame_bytes;
+    uint32_t s[4] = {0, 0, 0, 0}, q[4] = {0, 0, 0, 0};
+    const uint32_t y0 = band * BAND_ROWS;
+#pragma unroll
+    for (int r = 0; r < BAND_ROWS; ++r) {
+        const uint32_t y = y0 + r;
+        if (y < a.height && x < a.width) {
+            const uint32_t v = load_px4(img + (size_t)y * a.gray_stride, x, a.width);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t p = (v >> (8 * c)) & 0xffu;
+                s[c] += p;
+                q[c] += p * p;
+            }
+        }
+    }
+    const size_t o = ((size_t)frame * a.n_bands + band) * a.band_pitch + x;
+    *reinterpret_cast<uint4*>(a.band_sum + o) = make_uint4(s[0], s[1], s[2], s[3]);
+    *reinterpret_cast<uint4*>(a.band_sq + o) = make_uint4(q[0], q[1], q[2], q[3]);
+}
+
+__global__ __launch_bounds__(256) void band_scan(IntegralArgs a) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x;
+    const uint32_t frame = blockIdx.y;
+    if (x >= a.band_pitch) return;
+    uint32_t s = 0;
+    uint64_t q = 0;
+    size_t o = (size_t)frame * a.n_bands * a.band_pitch + x;
+    for (uint32_t b = 0; b < a.n_bands; ++b, o += a.band_pitch) {
+        const uint32_t ts = a.band_sum[o];
+        const uint32_t tq = a.band_sq[o];
+        a.band_sum[o] = s;         // exclusive prefix, in place
+        a.band_sq_prefix[o] = q;
+        s += ts;
+        q += tq;
+    }
+}
+
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, uint32_t lane) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint64_t t = __shfl_up(v, d, 64);
+        if (lane >= (uint32_t)d) v += t;
+    }
+    return v;
+}
+
+__global__ __launch_bounds__(256) void band_rows(IntegralArgs a) {
+    const uint32_t lane = lane_id();
+    const uint32_t band = blockIdx.x * 4u + (threadIdx.x >> 6);
+    const uint32_t frame = blockIdx.y;
+    if (band >= a.n_bands) return;  // whole wave exits together
+    const uint8_t* img = a.gray + (size_t)frame * a.gray_frame_bytes;
+    uint32_t* sum = a.sum + (size_t)frame * a.frame_elems;
+    uint64_t* sqs = a.sqsum + (size_t)frame * a.frame_elems;
+    const uint32_t ow = a.width + 1u;   // output row length
+    const uint32_t y0 = band * BAND_ROWS;
+    const size_t bo = ((size_t)frame * a.n_bands + band) * a.band_pitch;
+
+    if (band == 0) {  // row 0 of both outputs is zero
+        for (uint32_t x = lane; x < ow; x += 64u) {
+            sum[x] = 0u;
+            sqs[x] = 0ull;
+        }
+    }
+    uint32_t rs[BAND_ROWS];  // per row: total of everything left of the current chunk
+    uint64_t rq[BAND_ROWS];
+#pragma unroll
+    for (int r = 0; r < BAND_ROWS; ++r) {
+        rs[r] = 0;
+        rq[r] = 0;
+    }
+    for (uint32_t x0 = 0; x0 < a.width; x0 += 256u) {
+        const uint32_t x = x0 + lane * 4u;
+        const bool in = x < a.width;
+        uint32_t cs[4] = {0, 0, 0, 0};
+        uint64_t cq[4] = {0, 0, 0, 0};
+        if (in) {  // running column totals start at the prefix over the bands above
+            const uint4 t = *reinterpret_cast<const uint4*>(a.band_sum + bo + x);
+            cs[0] = t.x; cs[1] = t.y; cs[2] = t.z; cs[3] = t.w;
+            const ulonglong2 u0 = *reinterpret_cast<const ulonglong2*>(a.band_sq_prefix + bo + x);
+            const ulonglong2 u1 = *reinterpret_cast<const ulonglong2*>(a.band_sq_prefix + bo + x + 2);
+            cq[0] = u0.x; cq[1] = u0.y; cq[2] = u1.x; cq[3] = u1.y;
+        }
+#pragma unroll
+        for (int r = 0; r < BAND_ROWS; ++r) {
+            const uint32_t y = y0 + r;
+            if (y < a.height) {  // uniform
+                const uint32_t v = in ? load_px4(img + (size_t)y * a.gray_stride, x, a.width) : 0u;
+                uint32_t ls[4];
+                uint64_t lq[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t p = (v >> (8 * c)) & 0xffu;
+                    cs[c] += p;
+                    cq[c] += (uint64_t)(p * p);
+                    ls[c] = cs[c] + (c ? ls[c - 1] : 0u);
+                    lq[c] = cq[c] + (c ? lq[c - 1] : 0ull);
+                }
+                const uint32_t is = wave_incl_scan(ls[3], lane);
+                const uint64_t iq = wave_incl_scan(lq[3], lane);
+                const uint32_t base_s = rs[r] + (is - ls[3]);
+                const uint64_t base_q = rq[r] + (iq - lq[3]);
+                const size_t ro = (size_t)(y + 1u) * ow;
+                if (x0 == 0 && lane == 0) {  // column 0 is zero
+                    sum[ro] = 0u;
+                    sqs[ro] = 0ull;
+                }
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    if (x + c < a.width) {
+                        sum[ro + x + c + 1u] = base_s + ls[c];
+                        sqs[ro + x + c + 1u] = base_q + lq[c];
+                    }
+                rs[r] += __shfl(is, 63, 64);
+                rq[r] += __shfl(iq, 63, 64);
+            }
+        }
+    }
+}
+
+int launch_integral(const IntegralArgs& a, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint32_t quads = a.band_pitch / 4u;
+    dim3 g1((quads + 255u) / 256u, a.n_bands, a.n_frames);
+    hipLaunchKernelGGL(band_colsum, g1, dim3(256), 0, stream, a);
+    dim3 g2((a.band_pitch + 255u) / 256u, a.n_frames, 1);
+    hipLaunchKernelGGL(band_scan, g2, dim3(256), 0, stream, a);
+    dim3 g3((a.n_bands + 3u) / 4u, a.n_frames, 1);
+    hipLaunchKernelGGL(band_rows, g3, dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+// ====================================================================== cascade
+
+// computeVariance (clod.cpp:418-446) for the window whose origin is element `e` of the
+// frame described by (sum_f, sq_f).
+__device__ __forceinline__ float window_variance(rsrc_t sum_f, rsrc_t sq_f, uint32_t e, uint32_t e_lt, uint32_t e_dw,
+                                                 uint32_t e_dh, float area, bool signed_mean) {
+    // corner offsets are uniform (scalar adds); the lane contributes e
+    const uint32_t c0 = e_lt, c1 = e_lt + e_dw, c2 = e_lt + e_dh, c3 = e_lt + e_dh + e_dw;
+    const uint32_t s = ld_u32(sum_f, e * 4u, c0 * 4u) - ld_u32(sum_f, e * 4u, c1 * 4u) - ld_u32(sum_f, e * 4u, c2 * 4u) +
+                       ld_u32(sum_f, e * 4u, c3 * 4u);
+    const uint64_t q = ld_u64(sq_f, e * 8u, c0 * 8u) - ld_u64(sq_f, e * 8u, c1 * 8u) - ld_u64(sq_f, e * 8u, c2 * 8u) +
+                       ld_u64(sq_f, e * 8u, c3 * 8u);
+    const float mean = (signed_mean ? (float)(int32_t)s : (float)s) / area;
+    float variance = (float)q;                       // u64 -> f32, round to nearest even
+    variance = (variance / area) - (mean * mean);    // separate divide, multiply, subtract
+    return variance >= 0.0f ? sqrtf(variance) : 1.0f;
+}
+
+// The weighted rectangle sums of one node (clod.cl:60-76) for the lane's window.
+__device__ __forceinline__ float node_rect_sum(rsrc_t img, const NodeRecDev& r, uint32_t off) {
+    const uint32_t lt0 = r[0], lt1 = r[1], lt2 = r[2];
+    const uint32_t dh0 = r[3], dh1 = r[4], dh2 = r[5];
+    const uint32_t dw0 = r[6] & 0xffffu, dw1 = r[6] >> 16, dw2 = r[7] & 0xffffu;
+    const float w0 = __uint_as_float(r[8]), w1 = __uint_as_float(r[9]), w2 = __uint_as_float(r[10]);
+    // u32 wrap-around on the four corners, one cast, one multiply per rectangle
+    const uint32_t r0 = ld_u32(img, off, lt0) - ld_u32(img, off, lt0 + dw0) - ld_u32(img, off, lt0 + dh0) +
+                        ld_u32(img, off, lt0 + dh0 + dw0);
+    const uint32_t r1 = ld_u32(img, off, lt1) - ld_u32(img, off, lt1 + dw1) - ld_u32(img, off, lt1 + dh1) +
+                        ld_u32(img, off, lt1 + dh1 + dw1);
+    // rect_sum = 0; rect_sum += t0; — the leading "0 +" only maps -0 to +0, which no
+    // comparison or later sum can observe, so it is elided.
+    float rect_sum = (float)r0 * w0;
+    rect_sum += (float)r1 * w1;
+    if (w2 != 0.0f) {  // uniform branch (clod.cl:70)
+        const uint32_t r2 = ld_u32(img, off, lt2) - ld_u32(img, off, lt2 + dw2) - ld_u32(img, off, lt2 + dh2) +
+                            ld_u32(img, off, lt2 + dh2 + dw2);
+        rect_sum += (float)r2 * w2;
+    }
+    return rect_sum;
+}
+
+// One stump-based stage on one window (clod.cl:49-82).  `tab` points at the stage's
+// first node record of the wave's scale; every table value is wave-uniform.
+__device__ __forceinline__ float stage_sum_stumps(rsrc_t img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
+                                                  float var) {
+    float stage_sum = 0.0f;
+    for (uint32_t j = 0; j < n_nodes; ++j) {
+        const NodeRecDev r = tab[j];
+        const float norm_threshold = __uint_as_float(r[11]) * var;
+        const float rect_sum = node_rect_sum(img, r, off);
+        // alpha[rect_sum >= norm_threshold]: alpha[0] = left_val, alpha[1] = right_val
+        stage_sum += (rect_sum >= norm_threshold) ? __uint_as_float(r[13]) : __uint_as_float(r[12]);
+    }
+    return stage_sum;
+}
+
+// Multi-node trees: icvEvalHidHaarClassifier's walk (tempcv.cpp:771-792) on the clod
+// f32 arithmetic.  Nodes of a tree are stored consecutively and a child always has a
+// larger index than its parent, so a tree is evaluated by visiting its records in
+// order, each with the lanes whose walk currently sits on it; the table stays uniform.
+__device__ __forceinline__ float stage_sum_trees(rsrc_t img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
+                                                 float var) {
+    float stage_sum = 0.0f;
+    uint32_t cur = 0;     // node (inside the current tree) this lane evaluates next
+    uint32_t k = 0;       // position of the record inside its tree (uniform)
+    float value = 0.0f;
+    bool done = false;
+    for (uint32_t j = 0; j < n_nodes; ++j) {
+        const NodeRecDev r = tab[j];
+        const uint32_t flags = r[7] >> 16;
+        if (!done && cur == k) {
+            const float t = __uint_as_float(r[11]) * var;
+            const float sum = node_rect_sum(img, r, off);
+            const bool go_left = sum < t;  // idx = sum < t ? left : right
+            const uint32_t nxt = go_left ? r[12] : r[13];
+            const bool is_node = go_left ? (flags & 1u) != 0u : (flags & 2u) != 0u;
+            if (is_node) {
+                cur = nxt;
+            } else {
+                value = __uint_as_float(nxt);
+                done = true;
+            }
+        }
+        ++k;
+        if (flags & 4u) {  // last record of the tree (uniform)
+            stage_sum += value;
+            cur = 0;
+            k = 0;
+            done = false;
+        }
+    }
+    return stage_sum;
+}
+
+template <bool TREES>
+__device__ __forceinline__ float stage_sum_of(rsrc_t img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
+                                              float var) {
+    if (TREES) return stage_sum_trees(img, tab, n_nodes, off, var);
+    return stage_sum_stumps(img, tab, n_nodes, off, var);
+}
+
+// Runs stages [a.stage_begin, a.stage_end) over the wave's LDS queue q[0..n) of one
+// scale, compacting survivors in place after every stage, then hands the survivors to
+// the next pass's global queue (or to the detection list).  Linear cascades
+// (on_pass = s + 1, on_fail = reject): every queued window is at the same stage.
+template <bool TREES, bool LAST, bool COUNT>
+__device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t img, QEntry* q, uint32_t n,
+                                                  uint32_t scale_slot, uint32_t table_first, uint32_t q_base,
+                                                  uint32_t lane) {
+    kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + table_first;
+    kptr<StageDev> stages = as_k(a.stages);
+    for (uint32_t s = a.stage_begin; s < a.stage_end && n != 0u; ++s) {
+        const uint32_t first_node = stages[s].first_node;
+        const uint32_t n_nodes = stages[s].n_nodes;
+        const float threshold = stages[s].threshold;
+        if (COUNT && lane == 0) atomicAdd(a.stage_entered + s, (unsigned long long)n);
+        kptr<NodeRecDev> tab = table + first_node;
+        uint32_t m = 0;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t i = base + lane;
+            const bool act = i < n;
+            const QEntry e = q[act ? i : 0u];
+            bool pass = false;
+            if (act) pass = stage_sum_of<TREES>(img, tab, n_nodes, e.off, e.var) >= threshold;
+            const unsigned long long mask = __ballot(pass);
+            __builtin_amdgcn_wave_barrier();   // every lane has read its entry before any lane overwrites
+            if (pass) q[m + mbcnt(mask)] = e;  // m + rank <= i: never ahead of the read cursor
+            m += (uint32_t)__popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+        }
+        n = m;
+    }
+    if (n == 0u) return;
+    if (LAST) {
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(a.det_count, n);
+        g = __builtin_amdgcn_readfirstlane(g);
+        for (uint32_t i = lane; i < n; i += 64u)
+            if (g + i < a.det_cap) a.det[g + i] = DetEntry{q[i].off, scale_slot};
+    } else {
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(a.q_out_count + scale_slot, n);
+        g = __builtin_amdgcn_readfirstlane(g);
+        for (uint32_t i = lane; i < n; i += 64u) a.q_out[(size_t)q_base + g + i] = q[i];
+    }
+}
+
+template <bool FROM_GRID, bool TREES, bool LAST, bool COUNT>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs a) {
+    __shared__ QEntry lds_q[WAVES_PER_BLOCK * UNIT_WINDOWS];
+    const uint32_t lane = lane_id();
+    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    QEntry* q = lds_q + wib * UNIT_WINDOWS;
+    const uint32_t rank = blockIdx.x * WAVES_PER_BLOCK + wib;
+    kptr<ScaleDev> scales = as_k(a.scales);
+    // the whole batch of sum images behind one descriptor (host keeps it below 4 GiB)
+    const rsrc_t img = make_rsrc(a.sum, a.sum_bytes);
+
+    if (FROM_GRID) {
+        kptr<UnitDev> units = as_k(a.units);
+        const uint32_t total_units = a.n_units * a.n_frames;
+        const uint32_t frame_bytes4 = a.frame_elems * 4u;
+        for (uint32_t u = rank; u < total_units; u += a.total_waves) {
+            const uint32_t frame = u / a.n_units;
+            const uint32_t r = u - frame * a.n_units;
+            const uint32_t slot = units[r].scale;
+            const uint32_t first = units[r].first;
+            const uint32_t count = units[r].count;
+            const float step = scales[slot].step;
+            const uint32_t nx = scales[slot].nx;
+            const uint32_t e_lt = scales[slot].e_lt, e_dw = scales[slot].e_dw, e_dh = scales[slot].e_dh;
+            const float area = scales[slot].area;
+            const size_t frame_off = (size_t)frame * a.frame_elems;
+            const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
+            const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
+            const uint32_t frame_bytes = frame * frame_bytes4;  // < 2^32, checked on the host
+            // precomputeWindows (clod.cpp:495-527): x = lrint(ix * step), row-major
+            for (uint32_t i0 = 0; i0 < count; i0 += 64u) {
+                const uint32_t i = i0 + lane;
+                if (i < count) {
+                    const uint32_t idx = first + i;
+                    const uint32_t iy = idx / nx;
+                    const uint32_t ix = idx - iy * nx;
+                    const uint32_t x = (uint32_t)__float2int_rn((float)ix * step);
+                    const uint32_t y = (uint32_t)__float2int_rn((float)iy * step);
+                    const uint32_t e = y * a.stride + x;
+                    QEntry en;
+                    en.var = window_variance(sum_f, sq_f, e, e_lt, e_dw, e_dh, area, a.signed_mean != 0u);
+                    en.off = frame_bytes + e * 4u;
+                    q[i] = en;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            run_stages_linear<TREES, LAST, COUNT>(a, img, q, count, slot, scales[slot].table_first,
+                                                  scales[slot].q_base, lane);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else {
+        kptr<uint32_t> counts = as_k(a.q_in_count);
+        uint32_t start = 0;  // chunks of all previous scales; chunk c of scale k is virtual unit start + c
+        for (uint32_t slot = 0; slot < a.n_scales; ++slot) {
+            const uint32_t cnt = counts[slot];
+            const uint32_t n_chunks = (cnt + UNIT_WINDOWS - 1u) / UNIT_WINDOWS;
+            const uint32_t q_base = scales[slot].q_base;
+            const uint32_t table_first = scales[slot].table_first;
+            // first chunk of this scale owned by this wave: start + c == rank (mod total_waves)
+            uint32_t c = (rank + a.total_waves - start % a.total_waves) % a.total_waves;
+            for (; c < n_chunks; c += a.total_waves) {
+                const uint32_t c0 = c * UNIT_WINDOWS;
+                const uint32_t n = min(cnt - c0, (uint32_t)UNIT_WINDOWS);
+                for (uint32_t i = lane; i < n; i += 64u) q[i] = a.q_in[(size_t)q_base + c0 + i];
+                __builtin_amdgcn_wave_barrier();
+                run_stages_linear<TREES, LAST, COUNT>(a, img, q, n, slot, table_first, q_base, lane);
+                __builtin_amdgcn_wave_barrier();
+            }
+            start += n_chunks;
+        }
+    }
+}
+
+template <bool FROM_GRID, bool TREES>
+static void launch_variant(const CascadeArgs& a, bool last, bool count, int n_blocks, hipStream_t stream) {
+    dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
+    if (last) {
+        if (count) hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, true>), g, b, 0, stream, a);
+        else       hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, false>), g, b, 0, stream, a);
+    } else {
+        if (count) hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, false, true>), g, b, 0, stream, a);
+        else       hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, false, false>), g, b, 0, stream, a);
+    }
+}
+
+int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool last, bool count, int n_blocks,
+                        void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (from_grid) {
+        if (trees) launch_variant<true, true>(a, last, count, n_blocks, stream);
+        else       launch_variant<true, false>(a, last, count, n_blocks, stream);
+    } else {
+        if (trees) launch_variant<false, true>(a, last, count, n_blocks, stream);
+        else       launch_variant<false, false>(a, last, count, n_blocks, stream);
+    }
+    return (int)hipGetLastError();
+}
+
+}  // namespace vj

@@ -1,0 +1,184 @@
+// Host-side planning: scale enumeration, per-scale window grid and the per-scale
+// feature table.  This is the reference's own host logic (it runs on the CPU in the
+// reference's OpenCL path too, clod.cpp:1198-1246) restated literally, because its
+// mixed round()/lrint()/float/double choices define which windows exist and which
+// weights the kernel multiplies by.  Compiled with -ffp-contract=off.
+#include "vj_internal.hpp"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+
+namespace vj {
+
+// round() on the f32 product, as `(cl_uint)round(int * float)` does (clod.cpp:387-388,
+// 404-407, 554-557): half away from zero, then conversion to unsigned.
+static inline uint32_t round_u32(float v) { return (uint32_t)std::round((double)v); }
+
+std::vector<vj_scale_info> plan_scales(const vj_cascade& c, int W, int H, const vj_params& p) {
+    std::vector<vj_scale_info> out;
+    const float sf = p.scale_factor;
+    const int w0 = c.win_w, h0 = c.win_h;
+    // Scale count loop (clod.cpp:1198-1204): float * int compared against int.
+    int count = 0;
+    for (float cs = 1; cs * (float)w0 < (float)(W - 10) && cs * (float)h0 < (float)(H - 10); cs *= sf) {
+        if (++count > 4096) break;  // scale_factor <= 1 would never terminate in the reference
+    }
+    float s = 1;
+    for (int k = 0; k < count; ++k, s *= sf) {
+        vj_scale_info si;
+        memset(&si, 0, sizeof(si));
+        si.scale_idx = k;
+        si.scale = s;
+        // setupScale (clod.cpp:371-415)
+        si.step = (float)std::max(2.0, (double)s);
+        si.win_w = (int32_t)round_u32((float)w0 * s);
+        si.win_h = (int32_t)round_u32((float)h0 * s);
+        bool ok = true;
+        if (si.win_w < p.min_w || si.win_h < p.min_h) ok = false;
+        if (p.max_w != 0 && si.win_w > p.max_w) ok = false;
+        if (p.max_h != 0 && si.win_h > p.max_h) ok = false;
+        if (si.win_w > W || si.win_h > H) ok = false;
+        if (ok) {
+            si.equ_x = (int32_t)round_u32(s);
+            si.equ_y = si.equ_x;
+            si.equ_w = (int32_t)round_u32((float)(w0 - 2) * s);
+            si.equ_h = (int32_t)round_u32((float)(h0 - 2) * s);
+            si.area = (uint32_t)(si.equ_w * si.equ_h);
+            // lrint of an int / float quotient: round-half-even in the default mode
+            si.nx = (int32_t)std::lrint((double)((float)(W - si.win_w) / si.step));
+            si.ny = (int32_t)std::lrint((double)((float)(H - si.win_h) / si.step));
+            if (si.nx < 0) si.nx = 0;
+            if (si.ny < 0) si.ny = 0;
+            si.accepted = 1;
+        }
+        out.push_back(si);
+    }
+    return out;
+}
+
+// precomputeKernelCascade (clod.cpp:529-578) for every node of the cascade, in flat
+// node order, into the 64-byte device record.
+int build_node_table(const vj_cascade& c, int width, const vj_scale_info& s, NodeRec* recs) {
+    const uint32_t stride = (uint32_t)width + 1u;
+    const float cs = s.scale;
+    const float area = (float)s.area;
+    for (size_t t = 0; t < c.trees.size(); ++t) {
+        const vj_tree_desc& td = c.trees[t];
+        for (int k = 0; k < td.n_nodes; ++k) {
+            const vj_node_desc& nd = c.nodes[td.first_node + k];
+            NodeRec& r = recs[td.first_node + k];
+            memset(&r, 0, sizeof(r));
+            if (nd.tilted) {
+                set_error("tilted features are not supported (clod ignores the flag, clod.cpp:460)");
+                return VJ_ERR_UNSUPPORTED;
+            }
+            if (nd.rect[0].weight == 0.0f || nd.rect[1].weight == 0.0f) {
+                set_error("node %d: rect 0 and rect 1 must both be weighted (clod.cl:60-68 reads both)",
+                          td.first_node + k);
+                return VJ_ERR_UNSUPPORTED;
+            }
+            float first_rect_area = 0.0f;
+            float sum_rect_area = 0.0f;
+            uint32_t dw[3] = {0, 0, 0};
+            for (int q = 0; q < 3; ++q) {
+                const float ow = nd.rect[q].weight;
+                if (ow != 0.0f) {
+                    const uint32_t rx = round_u32((float)nd.rect[q].x * cs);
+                    const uint32_t ry = round_u32((float)nd.rect[q].y * cs);
+                    const uint32_t rw = round_u32((float)nd.rect[q].w * cs);
+                    const uint32_t rh = round_u32((float)nd.rect[q].h * cs);
+                    const float wgt = ow / area;
+                    const uint64_t lt = ((uint64_t)ry * stride + rx) * 4u;
+                    const uint64_t dh = (uint64_t)rh * stride * 4u;
+                    if (lt > 0xffffffffull || dh > 0xffffffffull || rw * 4u > 0xffffu) {
+                        set_error("feature offsets exceed the device record range");
+                        return VJ_ERR_LIMIT;
+                    }
+                    r.lt[q] = (uint32_t)lt;
+                    r.dh[q] = (uint32_t)dh;
+                    dw[q] = rw * 4u;
+                    r.w[q] = wgt;
+                    if (q > 0)
+                        sum_rect_area += wgt * (float)rw * (float)rh;
+                    else
+                        first_rect_area = (float)(rw * rh);
+                } else {
+                    r.w[q] = 0.0f;
+                }
+            }
+            r.w[0] = -sum_rect_area / first_rect_area;
+            r.thr = nd.threshold;
+            uint32_t flags = 0;
+            auto leaf_or_node = [&](int v, uint32_t flag, uint32_t* dst) {
+                if (v > 0) {
+                    flags |= flag;
+                    *dst = (uint32_t)v;
+                } else {
+                    const float a = c.alpha[td.first_alpha - v];
+                    memcpy(dst, &a, 4);
+                }
+            };
+            leaf_or_node(nd.left, NODE_LEFT_IS_NODE, &r.left);
+            leaf_or_node(nd.right, NODE_RIGHT_IS_NODE, &r.right);
+            if (k == td.n_nodes - 1) flags |= NODE_TREE_LAST;
+            r.dw01 = dw[0] | (dw[1] << 16);
+            r.dw2_flags = dw[2] | (flags << 16);
+        }
+    }
+    return VJ_OK;
+}
+
+}  // namespace vj
+
+using namespace vj;
+
+extern "C" {
+
+int vj_plan_scales(const vj_cascade* c, int width, int height, const vj_params* p, vj_scale_info* out, int cap,
+                   int* n) {
+    if (!c || !p || !n || width <= 0 || height <= 0 || (cap > 0 && !out)) return VJ_ERR_ARG;
+    if (!(p->scale_factor > 1.0f)) {
+        set_error("scale_factor must be > 1");
+        return VJ_ERR_ARG;
+    }
+    std::vector<vj_scale_info> v = plan_scales(*c, width, height, *p);
+    *n = (int)v.size();
+    for (int i = 0; i < *n && i < cap; ++i) out[i] = v[i];
+    return VJ_OK;
+}
+
+int vj_plan_feature_table(const vj_cascade* c, int width, const vj_scale_info* s, uint32_t* offsets, float* weights) {
+    if (!c || !s || !offsets || !weights || width <= 0 || !s->accepted) return VJ_ERR_ARG;
+    std::vector<NodeRec> recs(c->nodes.size());
+    int rc = build_node_table(*c, width, *s, recs.data());
+    if (rc) return rc;
+    // Expand the compact record back into the reference's KernelOptimizedRect fields
+    // (clod.cpp:45-51): four element offsets per rect.
+    for (size_t i = 0; i < recs.size(); ++i) {
+        const NodeRec& r = recs[i];
+        const uint32_t dw[3] = {r.dw01 & 0xffffu, r.dw01 >> 16, r.dw2_flags & 0xffffu};
+        for (int q = 0; q < 3; ++q) {
+            uint32_t* o = offsets + i * 12 + q * 4;
+            const bool present = q < 2 || r.w[2] != 0.0f;
+            o[0] = present ? r.lt[q] / 4u : 0u;
+            o[1] = present ? (r.lt[q] + dw[q]) / 4u : 0u;
+            o[2] = present ? (r.lt[q] + r.dh[q]) / 4u : 0u;
+            o[3] = present ? (r.lt[q] + r.dh[q] + dw[q]) / 4u : 0u;
+            weights[i * 3 + q] = r.w[q];
+        }
+    }
+    return VJ_OK;
+}
+
+int vj_count_windows(const vj_cascade* c, int width, int height, const vj_params* p, uint64_t* out) {
+    if (!c || !p || !out || width <= 0 || height <= 0) return VJ_ERR_ARG;
+    if (!(p->scale_factor > 1.0f)) return VJ_ERR_ARG;
+    uint64_t total = 0;
+    for (const vj_scale_info& s : plan_scales(*c, width, height, *p))
+        if (s.accepted) total += (uint64_t)s.nx * (uint64_t)s.ny;
+    *out = total;
+    return VJ_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,210 @@
+/*
+ * vj.h — C ABI of the MI355X-native Viola–Jones detect path (libvjhip.so).
+ *
+ * This is the drop-in boundary for the reference's clif/clod detect path
+ * (GabrieleCocco/CLFaceDetection).  Every entry point names the reference
+ * interface it replaces (file:line, relative to CLFaceDetection/).  The
+ * reference's own boundary is C++ with OpenCV/OpenCL types; neither exists on
+ * the target, so this header uses plain pointers, sizes and POD structs only
+ * (no torch types, no C++ types).  Errors are integer return codes — the
+ * reference calls exit() through clCheckOrExit (clod.cpp:114…); this library
+ * never exits the process.
+ *
+ * There is NO CPU fallback behind these calls: every function that computes on
+ * images runs hand-written HIP kernels on a gfx950 device and fails with
+ * VJ_ERR_NO_DEVICE when none is usable.  Host-only helpers (cascade loading,
+ * scale planning, feature-table construction) are the reference's host logic
+ * (clod.cpp:371-415, 529-578) and run on the CPU in the reference too.
+ */
+#ifndef VJ_H_
+#define VJ_H_
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+#if defined(VJ_BUILDING) && defined(__GNUC__)
+#pragma GCC visibility push(default)   /* only the names declared here are exported */
+#endif
+
+/* ------------------------------------------------------------------ errors */
+enum {
+    VJ_OK = 0,
+    VJ_ERR_ARG = 1,         /* null / out-of-range argument                      */
+    VJ_ERR_IO = 2,          /* file cannot be opened / read / written            */
+    VJ_ERR_PARSE = 3,       /* malformed cascade file                            */
+    VJ_ERR_UNSUPPORTED = 4, /* e.g. tilted features (clod ignores them; we refuse) */
+    VJ_ERR_NO_DEVICE = 5,   /* no usable HIP device                              */
+    VJ_ERR_HIP = 6,         /* a HIP runtime call failed (see vj_last_error)     */
+    VJ_ERR_NOMEM = 7,
+    VJ_ERR_LIMIT = 8        /* image / batch exceeds an addressing limit         */
+};
+const char* vj_strerror(int code);
+/* Thread-local detail string for the last failing call on this thread. */
+const char* vj_last_error(void);
+
+/* ----------------------------------------------------------------- cascade */
+/* Replaces cvLoad(xml) → CvHaarClassifierCascade* (main.cpp:36; loader spec
+ * tempcv.cpp:1749-2089, struct layout tempcv.hpp:70-112).                      */
+typedef struct vj_cascade vj_cascade;
+
+typedef struct vj_cascade_info {
+    int32_t win_w, win_h;      /* orig_window_size                              */
+    int32_t n_stages, n_trees, n_nodes, n_alpha;
+    int32_t max_trees_per_stage, max_nodes_per_tree;
+    int32_t n_tilted;          /* nodes with <tilted>1                          */
+    int32_t n_three_rect;      /* nodes with 3 rectangles                       */
+    int32_t is_stump_based;    /* every tree has exactly one node               */
+    int32_t is_stage_tree;     /* some stage has next != -1                     */
+} vj_cascade_info;
+
+typedef struct vj_stage_desc {  /* CvHaarStageClassifier (tempcv.hpp:95-105)    */
+    int32_t first_tree, n_trees;
+    float   threshold;
+    int32_t parent, next, child;
+} vj_stage_desc;
+
+typedef struct vj_rect_desc { int32_t x, y, w, h; float weight; } vj_rect_desc;
+
+typedef struct vj_node_desc {   /* one node of a CvHaarClassifier (tempcv.hpp:81-93) */
+    int32_t n_rects;            /* 2 or 3 (rects with weight != 0)              */
+    int32_t tilted;
+    float   threshold;
+    int32_t left, right;        /* >0: node index inside the tree; <=0: alpha[-v] */
+    vj_rect_desc rect[3];
+} vj_node_desc;
+
+typedef struct vj_tree_desc { int32_t first_node, n_nodes, first_alpha; } vj_tree_desc;
+
+/* OpenCV old-format XML (<opencv_storage><NAME type_id="opencv-haar-classifier">). */
+int  vj_cascade_load_xml(const char* path, vj_cascade** out);
+/* Compact binary form shipped under clfacedetection_amd/data (*.vjc). */
+int  vj_cascade_load(const char* path, vj_cascade** out);
+int  vj_cascade_save(const vj_cascade* c, const char* path);
+void vj_cascade_free(vj_cascade* c);
+int  vj_cascade_get_info(const vj_cascade* c, vj_cascade_info* out);
+/* Read-only views into the flat arrays (valid until vj_cascade_free). */
+const vj_stage_desc* vj_cascade_stages(const vj_cascade* c);
+const vj_tree_desc*  vj_cascade_trees(const vj_cascade* c);
+const vj_node_desc*  vj_cascade_nodes(const vj_cascade* c);
+const float*         vj_cascade_alpha(const vj_cascade* c);
+const char*          vj_cascade_notice(const vj_cascade* c);  /* license text of the source XML */
+
+/* ------------------------------------------------------------------ params */
+/* Arguments of clodDetectObjects (clod.h:72-81) that are not the image/cascade. */
+enum {
+    VJ_FLAG_COUNTERS     = 1u << 0, /* fill vj_result.counters + stage_entered   */
+    VJ_FLAG_SIGNED_MEAN  = 1u << 1, /* reproduce clod.cpp:426 literally: window
+                                       pixel sum read through int* (differs from
+                                       the default unsigned read only when the
+                                       sum >= 2^31)            */
+    VJ_FLAG_TABLE_IN_LDS = 1u << 2  /* stage tables staged in LDS instead of the
+                                       scalar cache (same results)               */
+};
+
+typedef struct vj_params {
+    int32_t  min_w, min_h;     /* min_window_size (0 = none)                    */
+    int32_t  max_w, max_h;     /* max_window_size (0 = unlimited, clod.cpp:394) */
+    float    scale_factor;     /* reference hard-codes 1.1f (clod.cpp:1184)     */
+    uint32_t min_neighbors;    /* 0 = raw candidates (the parity contract)      */
+    uint32_t flags;
+} vj_params;
+void vj_params_default(vj_params* p);   /* {0,0,0,0,1.1f,0,0} */
+
+/* ------------------------------------------------------ host scale planning */
+/* setupScale + scale enumeration (clod.cpp:371-415, 1198-1204). */
+typedef struct vj_scale_info {
+    int32_t  scale_idx;        /* k in s_k = fl32(s_{k-1} * scale_factor)       */
+    float    scale;            /* s_k                                           */
+    float    step;             /* (float)MAX(2.0, s)                            */
+    int32_t  win_w, win_h;     /* scaled_window_size                            */
+    int32_t  equ_x, equ_y, equ_w, equ_h;  /* equ_rect                           */
+    uint32_t area;             /* scaled_window_area                            */
+    int32_t  nx, ny;           /* end_point: window grid is [0,nx) x [0,ny)     */
+    int32_t  accepted;         /* 0 when setupScale returned -1                 */
+} vj_scale_info;
+/* Writes up to cap entries (all enumerated scales, accepted or not); *n = count. */
+int vj_plan_scales(const vj_cascade* c, int width, int height, const vj_params* p,
+                   vj_scale_info* out, int cap, int* n);
+
+/* precomputeKernelCascade (clod.cpp:529-578) for one scale: per node, 3 rects of
+ * {left_top, right_top, left_bottom, right_bottom element offsets, weight}.
+ * `offsets` receives n_nodes*12 uint32, `weights` n_nodes*3 floats.            */
+int vj_plan_feature_table(const vj_cascade* c, int width, const vj_scale_info* s,
+                          uint32_t* offsets, float* weights);
+
+/* ------------------------------------------------------------- environment */
+/* clodInitEnvironment/clodReleaseEnvironment (clod.h:61-65, clod.cpp:72-100,
+ * 173-180) — one env per device; not thread-safe (neither is the reference).   */
+typedef struct vj_env vj_env;
+int  vj_env_create(int device_index, vj_env** out);
+void vj_env_destroy(vj_env* e);
+/* clodInitBuffers + clifInitBuffers (clod.cpp:102-163, clif.cpp:105-224):
+ * pre-size device buffers; optional — vj_detect grows them on demand.          */
+int  vj_env_reserve(vj_env* e, int max_w, int max_h, int max_batch);
+int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
+
+/* --------------------------------------------------------------- integral */
+/* clifIntegral (clif.h:63-66, clif.cpp:273-285 → cvIntegral layout):
+ * sum u32 and sqsum u64, both (h+1) x (w+1) row-major, row 0 / col 0 zero.
+ * `gray`, `sum`, `sqsum` are HOST pointers (the reference returns host CvMat).  */
+int vj_integral(vj_env* e, const uint8_t* gray, int w, int h, int stride,
+                uint32_t* sum, uint64_t* sqsum);
+
+/* ----------------------------------------------------------------- detect */
+typedef struct vj_image {
+    const uint8_t* data;       /* 8-bit single channel                          */
+    int32_t width, height;
+    int32_t stride;            /* bytes per row                                 */
+    int32_t on_device;         /* 0: host pointer; 1: device pointer on env's GPU */
+} vj_image;
+
+typedef struct vj_rect {       /* CLODWeightedRect (clod.h:39-42) + provenance  */
+    int32_t x, y, w, h;
+    float   weight;            /* reference leaves it unset/0 for raw results   */
+    int32_t frame;
+    int32_t scale_idx;
+} vj_rect;
+
+#define VJ_MAX_STAGES 64
+typedef struct vj_counters {
+    uint64_t windows;          /* candidate windows enumerated                  */
+    uint64_t stump_evals;      /* tree-node evaluations                         */
+    uint64_t gather_bytes;     /* 48*windows + 16*sum(nrects)   */
+    uint64_t stage_entered[VJ_MAX_STAGES]; /* windows entering each stage       */
+} vj_counters;
+
+typedef struct vj_timing {     /* HIP-event times of the last vj_detect, ms     */
+    float integral_ms;
+    float cascade_ms;          /* all cascade passes                            */
+    float total_ms;            /* first kernel start → last kernel end          */
+    int32_t n_cascade_launches;
+} vj_timing;
+
+typedef struct vj_result {
+    vj_rect*   rects;          /* sorted by (frame, scale_idx, y, x)            */
+    uint32_t   count;
+    vj_counters counters;      /* valid when VJ_FLAG_COUNTERS                   */
+    vj_timing  timing;
+} vj_result;
+
+/* clodDetectObjects(image, cascade, data, min, max, min_neighbors, flags, CL_TRUE)
+ * (clod.h:72-81, clod.cpp:1176-1336), batched over n_frames frames of equal size. */
+int  vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames,
+               const vj_params* p, vj_result* out);
+void vj_result_free(vj_result* r);
+
+/* Candidate windows per frame for (cascade, size, params): sum of nx*ny over
+ * accepted scales — the denominator of the windows/s metric.                   */
+int vj_count_windows(const vj_cascade* c, int width, int height, const vj_params* p,
+                     uint64_t* out);
+
+#if defined(VJ_BUILDING) && defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
+#ifdef __cplusplus
+}
+#endif
+#endif /* VJ_H_ */

@@ -1,0 +1,405 @@
+/*
+ * vj_oracle.c — CPU restatement of the reference's clif/clod detect path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under clfacedetection_amd/ may import, link or
+ * call this file; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
+ * leg use it, and there only as the checker / reported CPU baseline.
+ *
+ * PARITY PINNING: the reference (GabrieleCocco/CLFaceDetection) ships no tests, no
+ * golden vectors and no fixtures, and cannot be built in this image (it needs the
+ * OpenCV 2.4.2 and CLUtil headers, which are absent; writing stand-ins for them is
+ * not allowed).  This restatement is therefore pinned only by (1) the known-answer
+ * constants in the reference's cascade XMLs and (2) the reference-run figures that
+ * the survey recorded in SURVEY.md §6/§8 (scale counts, candidate-window counts,
+ * per-stage survivor counts, stump-evaluation totals, raw detection counts) — see
+ * tests/test_oracle_pins.py.  For tree cascades (frontalface_alt2, _alt_tree) the
+ * reference's clod path itself is wrong (SURVEY.md §2.2-3,4): parity there is
+ * UNPINNED beyond this file and its numpy twin (oracle/np_oracle.py).
+ *
+ * Every function cites the reference lines it follows (paths relative to
+ * CLFaceDetection/).  All float arithmetic is IEEE binary32 in the written order;
+ * build with -ffp-contract=off (see oracle/Makefile).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ types */
+typedef struct oc_cascade {
+    int32_t win_w, win_h;
+    int32_t n_stages, n_trees, n_nodes, n_alpha;
+    /* per stage — CvHaarStageClassifier (tempcv.hpp:95-105) */
+    const int32_t* stage_first_tree;
+    const int32_t* stage_n_trees;
+    const float*   stage_threshold;
+    const int32_t* stage_parent;
+    const int32_t* stage_next;
+    const int32_t* stage_child;
+    /* per tree — CvHaarClassifier (tempcv.hpp:81-93) */
+    const int32_t* tree_first_node;
+    const int32_t* tree_n_nodes;
+    const int32_t* tree_first_alpha;
+    /* per node */
+    const int32_t* node_rect;      /* n_nodes * 3 * 4 : x y w h                 */
+    const float*   node_weight;    /* n_nodes * 3 (0 = rect absent)             */
+    const float*   node_threshold;
+    const int32_t* node_left;      /* >0 node index, <=0 -> alpha[-v]           */
+    const int32_t* node_right;
+    const float*   alpha;
+} oc_cascade;
+
+typedef struct oc_scale {
+    int32_t scale_idx;
+    float   scale, step;
+    int32_t win_w, win_h;
+    int32_t equ_x, equ_y, equ_w, equ_h;
+    uint32_t area;
+    int32_t nx, ny;
+    int32_t accepted;
+} oc_scale;
+
+typedef struct oc_rect { int32_t x, y, w, h, scale_idx; } oc_rect;
+
+typedef struct oc_stats {
+    uint64_t windows;
+    uint64_t stump_evals;
+    uint64_t rect_evals;           /* sum of rect count over evaluated nodes    */
+    uint64_t stage_entered[64];
+} oc_stats;
+
+/* ------------------------------------------------- a1: integral (cvIntegral) */
+/* clifIntegral / clifGrayscaleIntegral host branch (clif.cpp:280-285, 326-335) call
+ * cvIntegral(gray, sum CV_32SC1, sqsum CV_64FC1), both (h+1)x(w+1), first row and
+ * column zero.  cvIntegral is exact integer arithmetic (OpenCV 2.4.2, not in the
+ * reference tree); sum wraps in 32 bits, sqsum is exact in double below 2^53.      */
+void oc_integral(const uint8_t* gray, int w, int h, int stride, int32_t* sum, double* sqsum) {
+    const int sw = w + 1;
+    for (int x = 0; x <= w; ++x) { sum[x] = 0; sqsum[x] = 0.0; }
+    for (int y = 0; y < h; ++y) {
+        const uint8_t* src = gray + (size_t)y * stride;
+        const int32_t* up = sum + (size_t)y * sw;
+        const double* upq = sqsum + (size_t)y * sw;
+        int32_t* row = sum + (size_t)(y + 1) * sw;
+        double* rowq = sqsum + (size_t)(y + 1) * sw;
+        uint32_t s = 0;
+        uint64_t q = 0;
+        row[0] = 0;
+        rowq[0] = 0.0;
+        for (int x = 0; x < w; ++x) {
+            const uint32_t v = src[x];
+            s += v;
+            q += (uint64_t)v * v;
+            row[x + 1] = (int32_t)((uint32_t)up[x + 1] + s);
+            rowq[x + 1] = upq[x + 1] + (double)q;
+        }
+    }
+}
+
+/* ------------------------------------------------------- a2: scale counting */
+/* clod.cpp:1198-1204 (same loop at :841-847, :1366-1372). */
+int oc_scale_count(int win_w, int win_h, int W, int H, float scale_factor) {
+    int scale_count = 0;
+    for (float current_scale = 1;
+         current_scale * win_w < W - 10 && current_scale * win_h < H - 10;
+         current_scale *= scale_factor) {
+        scale_count++;
+        if (scale_count > 4096) break;
+    }
+    return scale_count;
+}
+
+/* ----------------------------------------------------------- a3: setupScale */
+/* clod.cpp:371-415.  Returns 0 when the scale is accepted, -1 otherwise. */
+int oc_setup_scale(float current_scale, int W, int H, int win_w, int win_h,
+                   int min_w, int min_h, int max_w, int max_h, oc_scale* out) {
+    memset(out, 0, sizeof(*out));
+    out->scale = current_scale;
+    /* :384  *step = MAX(2.0, (float)current_scale);  (double max, stored to float) */
+    double stepd = 2.0 > (double)current_scale ? 2.0 : (double)current_scale;
+    out->step = (float)stepd;
+    /* :387-388 */
+    out->win_w = (int32_t)(uint32_t)round(win_w * current_scale);
+    out->win_h = (int32_t)(uint32_t)round(win_h * current_scale);
+    /* :391-401 */
+    if (out->win_w < min_w || out->win_h < min_h) return -1;
+    if (max_w != 0 && out->win_w > max_w) return -1;
+    if (max_h != 0 && out->win_h > max_h) return -1;
+    if (out->win_w > W || out->win_h > H) return -1;
+    /* :404-408 */
+    out->equ_x = (int32_t)(uint32_t)round(current_scale);
+    out->equ_y = out->equ_x;
+    out->equ_w = (int32_t)(uint32_t)round((win_w - 2) * current_scale);
+    out->equ_h = (int32_t)(uint32_t)round((win_h - 2) * current_scale);
+    out->area = (uint32_t)(out->equ_w * out->equ_h);
+    /* :411-412 */
+    out->nx = (int)lrint((W - out->win_w) / out->step);
+    out->ny = (int)lrint((H - out->win_h) / out->step);
+    out->accepted = 1;
+    return 0;
+}
+
+/* ------------------------------------------------- a5: per-scale feature table */
+/* KernelOptimizedRect / KernelClassifier (clod.cpp:45-57) per NODE. */
+typedef struct k_rect { uint32_t lt, rt, lb, rb; float weight; } k_rect;
+typedef struct k_node { k_rect rect[3]; float threshold; } k_node;
+
+/* precomputeKernelCascade (clod.cpp:529-578), applied to every node's feature. */
+static void precompute_nodes(const oc_cascade* c, float current_scale, uint32_t area,
+                             uint32_t ii_width, k_node* out) {
+    for (int n = 0; n < c->n_nodes; ++n) {
+        float first_rect_area = 0;
+        float sum_rect_area = 0;
+        for (int r = 0; r < 3; ++r) {
+            float original_weight = c->node_weight[n * 3 + r];
+            if (original_weight != 0) {
+                const int32_t* orc = c->node_rect + (n * 3 + r) * 4;
+                uint32_t rect_x = (uint32_t)round(orc[0] * current_scale);
+                uint32_t rect_y = (uint32_t)round(orc[1] * current_scale);
+                uint32_t rect_width = (uint32_t)round(orc[2] * current_scale);
+                uint32_t rect_height = (uint32_t)round(orc[3] * current_scale);
+                float rect_weight = original_weight / (float)area;
+                out[n].rect[r].lt = ii_width * rect_y + rect_x;
+                out[n].rect[r].rt = ii_width * rect_y + rect_x + rect_width;
+                out[n].rect[r].lb = ii_width * (rect_y + rect_height) + rect_x;
+                out[n].rect[r].rb = ii_width * (rect_y + rect_height) + rect_x + rect_width;
+                out[n].rect[r].weight = rect_weight;
+                if (r > 0)
+                    sum_rect_area += rect_weight * rect_width * rect_height;
+                else
+                    first_rect_area = rect_width * rect_height;
+            } else {
+                out[n].rect[r].lt = out[n].rect[r].rt = out[n].rect[r].lb = out[n].rect[r].rb = 0;
+                out[n].rect[r].weight = 0;
+            }
+        }
+        out[n].rect[0].weight = (-sum_rect_area / first_rect_area);
+        out[n].threshold = c->node_threshold[n];
+    }
+}
+
+/* Exported for the table tests: offsets[n*12 + r*4 + {lt,rt,lb,rb}], weights[n*3+r]. */
+void oc_feature_table(const oc_cascade* c, float current_scale, uint32_t area, int W,
+                      uint32_t* offsets, float* weights) {
+    k_node* kn = (k_node*)malloc(sizeof(k_node) * (size_t)c->n_nodes);
+    precompute_nodes(c, current_scale, area, (uint32_t)W + 1u, kn);
+    for (int n = 0; n < c->n_nodes; ++n)
+        for (int r = 0; r < 3; ++r) {
+            offsets[n * 12 + r * 4 + 0] = kn[n].rect[r].lt;
+            offsets[n * 12 + r * 4 + 1] = kn[n].rect[r].rt;
+            offsets[n * 12 + r * 4 + 2] = kn[n].rect[r].lb;
+            offsets[n * 12 + r * 4 + 3] = kn[n].rect[r].rb;
+            weights[n * 3 + r] = kn[n].rect[r].weight;
+        }
+    free(kn);
+}
+
+/* --------------------------------------------------------- a4: the window list */
+typedef struct k_window { uint32_t x, y, offset; float variance; } k_window; /* clod.cpp:33-38 */
+
+/* computeVariance (clod.cpp:418-446).  signed_mean != 0 reads the pixel sum through
+ * int* exactly as :426 does; 0 reads it unsigned.               */
+static float compute_variance(const int32_t* sum, const double* sqsum, uint32_t ii_width,
+                              const oc_scale* sc, uint32_t px, uint32_t py, int signed_mean) {
+    const size_t x0 = (size_t)px + sc->equ_x, y0 = (size_t)py + sc->equ_y;
+    const size_t w = sc->equ_w, h = sc->equ_h;
+    const size_t a = ii_width * y0 + x0, b = ii_width * y0 + x0 + w;
+    const size_t c = ii_width * (y0 + h) + x0, d = ii_width * (y0 + h) + x0 + w;
+    float mean;
+    if (signed_mean) {
+        int32_t s = (int32_t)((uint32_t)sum[a] - (uint32_t)sum[b] - (uint32_t)sum[c] + (uint32_t)sum[d]);
+        mean = (float)s / (float)sc->area;
+    } else {
+        uint32_t s = (uint32_t)sum[a] - (uint32_t)sum[b] - (uint32_t)sum[c] + (uint32_t)sum[d];
+        mean = (float)s / (float)sc->area;
+    }
+    /* matss: each corner cast to unsigned long, then summed (clod.cpp:20-21, 432) */
+    unsigned long q = (unsigned long)sqsum[a] - (unsigned long)sqsum[b] - (unsigned long)sqsum[c] +
+                      (unsigned long)sqsum[d];
+    float variance = (float)q;
+    variance = (variance / (float)sc->area) - (mean * mean);
+    if (variance >= 0)
+        variance = sqrtf(variance);
+    else
+        variance = 1;
+    return variance;
+}
+
+/* precomputeWindows (clod.cpp:495-527): row-major, x = lrint(ix * step). */
+static uint32_t precompute_windows(const int32_t* sum, const double* sqsum, uint32_t ii_width,
+                                   const oc_scale* sc, int signed_mean, k_window* out) {
+    uint32_t n = 0;
+    for (int y_index = 0; y_index < sc->ny; y_index++) {
+        for (int x_index = 0; x_index < sc->nx; x_index++) {
+            uint32_t px = (uint32_t)lrint(x_index * sc->step);
+            uint32_t py = (uint32_t)lrint(y_index * sc->step);
+            out[n].x = px;
+            out[n].y = py;
+            out[n].variance = compute_variance(sum, sqsum, ii_width, sc, px, py, signed_mean);
+            out[n].offset = ii_width * py + px;
+            n++;
+        }
+    }
+    return n;
+}
+
+/* ------------------------------------------------------------- a6: runStage */
+static inline float rect_term(const uint32_t* ii, uint32_t o, const k_rect* r) {
+    /* u32 wrap-around on the four corners, then one cast, then one multiply (clod.cl:60-63) */
+    return (float)(ii[o + r->lt] - ii[o + r->rt] - ii[o + r->lb] + ii[o + r->rb]) * r->weight;
+}
+
+static inline float node_sum(const uint32_t* ii, uint32_t o, const k_node* k) {
+    float rect_sum = 0;
+    rect_sum += rect_term(ii, o, &k->rect[0]);
+    rect_sum += rect_term(ii, o, &k->rect[1]);
+    if (k->rect[2].weight != 0) rect_sum += rect_term(ii, o, &k->rect[2]);
+    return rect_sum;
+}
+
+/* One stage on one window.  Stumps: clod.cl:49-82 (alpha[rect_sum >= norm_threshold]).
+ * Multi-node trees: icvEvalHidHaarClassifier control flow (tempcv.cpp:771-792) on the
+ * clod f32 arithmetic.                                           */
+static float stage_sum_for(const oc_cascade* c, const k_node* kn, const uint32_t* ii,
+                           const k_window* w, int stage, oc_stats* st) {
+    float stage_sum = 0;
+    const int t0 = c->stage_first_tree[stage], t1 = t0 + c->stage_n_trees[stage];
+    for (int t = t0; t < t1; ++t) {
+        const int n0 = c->tree_first_node[t];
+        const float* alpha = c->alpha + c->tree_first_alpha[t];
+        if (c->tree_n_nodes[t] == 1) {
+            const k_node* k = kn + n0;
+            float norm_threshold = k->threshold * w->variance;
+            float rect_sum = node_sum(ii, w->offset, k);
+            stage_sum += alpha[rect_sum >= norm_threshold];
+            st->stump_evals++;
+            st->rect_evals += (k->rect[2].weight != 0) ? 3 : 2;
+        } else {
+            int idx = 0;
+            do {
+                const k_node* k = kn + n0 + idx;
+                float tt = k->threshold * w->variance;
+                float sum = node_sum(ii, w->offset, k);
+                st->stump_evals++;
+                st->rect_evals += (k->rect[2].weight != 0) ? 3 : 2;
+                idx = sum < tt ? c->node_left[n0 + idx] : c->node_right[n0 + idx];
+            } while (idx > 0);
+            stage_sum += alpha[-idx];
+        }
+    }
+    return stage_sum;
+}
+
+/* Detect on one frame.
+ *  mode 0: per-stage list compaction, the OpenCL driver's structure (clod.cpp:1212-1322,
+ *          runStage clod.cl:32-93) with the intended ping-pong / zeroed counter
+ *          (SURVEY.md §2.2-1,2).  Linear cascades only.
+ *  mode 1: per-window walk of the stage tree (tempcv.cpp:834-861): pass -> child,
+ *          fail -> climb parents until a next sibling exists, else reject; falling
+ *          off the end accepts.  Works for linear cascades too (child = next stage).
+ * Returns the number of rects written (at most cap; the true count is in *n_total). */
+int oc_detect(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride,
+              int min_w, int min_h, int max_w, int max_h, float scale_factor,
+              int signed_mean, int mode,
+              oc_rect* out, int cap, int* n_total, oc_stats* st) {
+    const uint32_t iw = (uint32_t)W + 1u;
+    /* +2 zero rows of slack so the one-column feature overshoot at the bottom-right
+     * corner reads defined zeros instead of past the allocation. */
+    int32_t* sum = (int32_t*)calloc((size_t)iw * (H + 3), sizeof(int32_t));
+    double* sqsum = (double*)calloc((size_t)iw * (H + 3), sizeof(double));
+    k_node* kn = (k_node*)malloc(sizeof(k_node) * (size_t)c->n_nodes);
+    memset(st, 0, sizeof(*st));
+    oc_integral(gray, W, H, stride, sum, sqsum);
+    const uint32_t* ii = (const uint32_t*)sum;
+
+    int found = 0;
+    const int scale_count = oc_scale_count(c->win_w, c->win_h, W, H, scale_factor);
+    float current_scale = 1;
+    for (int scale_index = 0; scale_index < scale_count; scale_index++, current_scale *= scale_factor) {
+        oc_scale sc;
+        if (oc_setup_scale(current_scale, W, H, c->win_w, c->win_h, min_w, min_h, max_w, max_h, &sc) != 0)
+            continue;
+        sc.scale_idx = scale_index;
+        precompute_nodes(c, current_scale, sc.area, iw, kn);
+        const size_t nwin = (size_t)(sc.nx > 0 ? sc.nx : 0) * (size_t)(sc.ny > 0 ? sc.ny : 0);
+        if (nwin == 0) continue;
+        k_window* a = (k_window*)malloc(sizeof(k_window) * nwin);
+        uint32_t n_in = precompute_windows(sum, sqsum, iw, &sc, signed_mean, a);
+        st->windows += n_in;
+        if (mode == 0) {
+            k_window* b = (k_window*)malloc(sizeof(k_window) * nwin);
+            uint32_t n_out = n_in;
+            for (int stage = 0; stage < c->n_stages; ++stage) {
+                st->stage_entered[stage] += n_in;
+                n_out = 0;
+                const float thr = c->stage_threshold[stage];
+                for (uint32_t g = 0; g < n_in; ++g) {
+                    float stage_sum = stage_sum_for(c, kn, ii, &a[g], stage, st);
+                    if (stage_sum >= thr) b[n_out++] = a[g];
+                }
+                k_window* t = a; a = b; b = t;
+                n_in = n_out;
+                if (n_out == 0) break;
+            }
+            for (uint32_t i = 0; i < n_out; ++i) {
+                if (found < cap) {
+                    out[found].x = (int32_t)a[i].x;
+                    out[found].y = (int32_t)a[i].y;
+                    out[found].w = sc.win_w;
+                    out[found].h = sc.win_h;
+                    out[found].scale_idx = scale_index;
+                }
+                found++;
+            }
+            free(b);
+        } else {
+            for (uint32_t g = 0; g < n_in; ++g) {
+                int ptr = 0, accept = 0;
+                while (ptr != -1) {
+                    st->stage_entered[ptr]++;
+                    float stage_sum = stage_sum_for(c, kn, ii, &a[g], ptr, st);
+                    if (stage_sum >= c->stage_threshold[ptr]) {
+                        ptr = c->stage_child[ptr];
+                        if (ptr == -1) accept = 1;
+                    } else {
+                        while (ptr != -1 && c->stage_next[ptr] == -1) ptr = c->stage_parent[ptr];
+                        if (ptr == -1) break;
+                        ptr = c->stage_next[ptr];
+                    }
+                }
+                if (accept) {
+                    if (found < cap) {
+                        out[found].x = (int32_t)a[g].x;
+                        out[found].y = (int32_t)a[g].y;
+                        out[found].w = sc.win_w;
+                        out[found].h = sc.win_h;
+                        out[found].scale_idx = scale_index;
+                    }
+                    found++;
+                }
+            }
+        }
+        free(a);
+    }
+    free(kn);
+    free(sum);
+    free(sqsum);
+    *n_total = found;
+    return found < cap ? found : cap;
+}
+
+/* ----------------------------------------------------- synthetic test images */
+/* The survey's generator: 32-bit xorshift (13,17,5); `noise` = low
+ * byte of the generator state after each step, row-major.                          */
+void oc_xorshift_noise(uint32_t seed, uint8_t* dst, size_t n) {
+    uint32_t s = seed ? seed : 1u;
+    for (size_t i = 0; i < n; ++i) {
+        s ^= s << 13;
+        s ^= s >> 17;
+        s ^= s << 5;
+        dst[i] = (uint8_t)(s & 0xffu);
+    }
+}
+
+/* u64 -> f32 conversion probe, for known-answer tests of the device conversion. */
+float oc_u64_to_f32(uint64_t v) { return (float)v; }
