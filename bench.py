@@ -1,0 +1,214 @@
+#!/usr/bin/env python3
+"""Headline benchmark of the MI355X-native Viola–Jones detect path.
+
+Metric (BASELINE.json): candidate windows/sec (+ Mpix/s) on 1080p frames with
+haarcascade_frontalface_alt, 1/2/4/8 GPUs.  A "step" is one pass of the whole hot path
+(integral + squared-integral kernels, all cascade passes, detection read-back and — for
+N > 1 — the all-gather of detection rectangles) over one batch of synthetic frames that
+is already resident in HBM.  Per-GPU work is fixed (weak scaling): every rank owns a
+batch of --frames 1080p frames; there is no data-path collective besides that gather.
+
+    python bench.py --gpus 1 --steps 20 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line.  `value` is whole-job windows/s over the K timed steps
+(max over ranks of the wall time, barrier + synchronize on both sides).  `roofline`
+is for the dominant kernel, the first cascade pass, from HIP events recorded inside the
+library on the stream the kernels run on.  `cpu_baseline` is the CPU oracle
+(oracle/vj_oracle.c, a single-threaded restatement of the reference's clod path) timed
+on a bounded sample of the same frames, and doubles as a parity check of that sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def main() -> int:
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=64, help="1080p frames per GPU per step")
+    ap.add_argument("--width", type=int, default=1920)
+    ap.add_argument("--height", type=int, default=1080)
+    ap.add_argument("--cascade", default="frontalface_alt")
+    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the batch timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--pass-split", default=None)
+    ap.add_argument("--blocks-per-cu", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run",
+                  file=sys.stderr)
+        return 2
+    if not torch.cuda.is_available():
+        print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
+        return 3
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from clfacedetection_amd import (VJ_FLAG_COUNTERS, Cascade, DeviceFrames, Environment, default_params, multigpu,
+                                     synth)
+
+    env = Environment(local_rank)
+    if args.pass_split is not None:
+        env.configure("pass_split", args.pass_split)
+    if args.blocks_per_cu is not None:
+        env.configure("blocks_per_cu", args.blocks_per_cu)
+    casc = Cascade.load(args.cascade)
+    H, W, B = args.height, args.width, args.frames
+
+    # synthetic frames (seeds 1.., kinds cycling noise / smooth / blocks), per rank
+    frames_h = synth.batch(B, H, W, seed0=1 + rank * B)
+    frames_d = torch.from_numpy(frames_h).to(dev)
+    torch.cuda.synchronize()
+    dframes = DeviceFrames.from_torch(frames_d)
+    windows_per_frame = casc.count_windows(W, H)
+
+    def step(params):
+        r = env.detect(casc, dframes, params)
+        rects = r.rects
+        if world > 1:
+            rects = rects.copy()
+            rects["frame"] += rank * B          # global frame index
+            rects = multigpu.allgather_rects(rects, device=dev)
+        return r, rects
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # one counted run: algorithmic bytes + the detections used for the parity sample
+    counted, _ = step(default_params(flags=VJ_FLAG_COUNTERS))
+    p = default_params()
+    for _ in range(args.warmup):
+        step(p)
+    barrier()
+    t0 = time.perf_counter()
+    integral_ms = cascade_ms = 0.0
+    pass_ms = None
+    n_det_total = 0
+    for _ in range(args.steps):
+        r, rects = step(p)
+        integral_ms += r.integral_ms
+        cascade_ms += r.cascade_ms
+        pm = [x[2] for x in r.passes]
+        pass_ms = pm if pass_ms is None else [a + b for a, b in zip(pass_ms, pm)]
+        n_det_total = len(rects)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    total_windows = windows_per_frame * B * world * args.steps
+    value = total_windows / elapsed
+    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+
+    out = None
+    if rank == 0:
+        K = max(args.steps, 1)
+        # ---- roofline of the dominant kernel: the first cascade pass (stages [0, k1))
+        # algorithmic bytes: 48 B per window for the variance gathers +
+        # 16 B per evaluated rectangle; per-stage populations come from the counted run.
+        nodes = casc.nodes
+        trees = casc.trees
+        stages = casc.stages
+        rects_per_stage = []
+        for s in stages:
+            tr = trees[s["first_tree"]:s["first_tree"] + s["n_trees"]]
+            rects_per_stage.append(int(sum(int(nodes["n_rects"][t["first_node"]:t["first_node"] + t["n_nodes"]].sum())
+                                           for t in tr)))
+        b0, e0, _ = counted.passes[0]
+        alg_bytes_pass0 = 48 * counted.windows + 16 * sum(counted.stage_entered[s] * rects_per_stage[s]
+                                                         for s in range(b0, e0))
+        pass0_ms = pass_ms[0] / K
+        achieved = alg_bytes_pass0 / (pass0_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_pass0.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": f"cascade_pass<from_grid> stages [{b0},{e0})",
+                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": int(alg_bytes_pass0), "avg_launch_ms": round(pass0_ms, 4)}
+
+        # ---- CPU baseline: the oracle, 1 thread, on the first --cpu-frames frames (also a parity check)
+        cpu = None
+        parity = None
+        if world == 1 and args.cpu_frames > 0:
+            from oracle.oracle import Oracle, load_vjc
+            from clfacedetection_amd.api import DATA_DIR
+            o = Oracle()
+            a = load_vjc(os.path.join(DATA_DIR, f"haarcascade_{args.cascade}.vjc"))
+            n_cpu = min(args.cpu_frames, B)
+            t1 = time.perf_counter()
+            parity = True
+            for f in range(n_cpu):
+                ro, _ = o.detect(a, frames_h[f])
+                mine = counted.rects[counted.rects["frame"] == f]
+                same = len(ro) == len(mine) and all(np.array_equal(ro[k], mine[k])
+                                                    for k in ("scale_idx", "x", "y", "w", "h"))
+                parity = parity and bool(same)
+            cpu_s = time.perf_counter() - t1
+            cpu = {"value": round(windows_per_frame * n_cpu / cpu_s, 1), "unit": "windows/s", "cores": 1,
+                   "kind": "port", "sample": f"first {n_cpu} of the {B} frames, {cpu_s:.1f} s, oracle/vj_oracle.c "
+                   f"(gcc -O2 -ffp-contract=off, integral + all scales + all stages)"}
+        out = {
+            "metric": "candidate windows/sec, 1080p, haarcascade_frontalface_alt",
+            "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32 gathers + f32 stage sums", "data": "synthetic",
+            "config": {"workload": f"{B}x{W}x{H} 8-bit frames per GPU per step (noise/smooth/blocks mix), "
+                                   f"haarcascade_{args.cascade}, scaleFactor 1.1f, raw candidates, frames resident in HBM",
+                       "frames_per_gpu": B, "windows_per_frame": windows_per_frame,
+                       "pass_split": [x[0] for x in counted.passes], "device": env.device_name},
+            "mpix_per_s": round(W * H * B * world * args.steps / elapsed / 1e6, 1),
+            "frames_per_s": round(B * world * args.steps / elapsed, 1),
+            "detections_last_step": int(n_det_total),
+            "kernel_ms_per_step": {"integral": round(integral_ms / K, 4), "cascade": round(cascade_ms / K, 4),
+                                   "cascade_passes": [round(x / K, 4) for x in pass_ms]},
+            "stump_evals_per_window": round(counted.stump_evals / max(counted.windows, 1), 3),
+            "cascade_algorithmic_GBps": round(counted.gather_bytes / (cascade_ms / K * 1e-3) / 1e9, 2),
+            "roofline": roofline, "cpu_baseline": cpu, "parity_sample_ok": parity,
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if out is not None:
+        print(json.dumps(out), flush=True)
+        if out["parity_sample_ok"] is False:
+            print("bench.py: PARITY FAILURE on the CPU sample", file=sys.stderr)
+            return 4
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

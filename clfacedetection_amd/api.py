@@ -54,7 +54,8 @@ class CascadeInfo(C.Structure):
 
 class Params(C.Structure):
     _fields_ = [("min_w", C.c_int32), ("min_h", C.c_int32), ("max_w", C.c_int32), ("max_h", C.c_int32),
-                ("scale_factor", C.c_float), ("min_neighbors", C.c_uint32), ("flags", C.c_uint32)]
+                ("scale_factor", C.c_float), ("min_neighbors", C.c_uint32), ("flags", C.c_uint32),
+                ("scale_mask", C.c_uint64 * 2)]
 
 
 class ScaleInfo(C.Structure):
@@ -74,9 +75,13 @@ class _Counters(C.Structure):
                 ("stage_entered", C.c_uint64 * VJ_MAX_STAGES)]
 
 
+VJ_MAX_PASSES = 8
+
+
 class _Timing(C.Structure):
     _fields_ = [("integral_ms", C.c_float), ("cascade_ms", C.c_float), ("total_ms", C.c_float),
-                ("n_cascade_launches", C.c_int32)]
+                ("n_cascade_launches", C.c_int32), ("pass_ms", C.c_float * VJ_MAX_PASSES),
+                ("pass_stage_begin", C.c_int32 * VJ_MAX_PASSES), ("pass_stage_end", C.c_int32 * VJ_MAX_PASSES)]
 
 
 class _Result(C.Structure):
@@ -115,6 +120,7 @@ _SIGNATURES = {
     "vj_env_destroy": (None, [C.c_void_p]),
     "vj_env_reserve": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int]),
     "vj_env_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
+    "vj_env_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "vj_integral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vj_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.POINTER(Params),
                             C.POINTER(_Result)]),
@@ -152,7 +158,11 @@ def default_params(**kw) -> Params:
     p = Params()
     load_library().vj_params_default(C.byref(p))
     for k, v in kw.items():
-        setattr(p, k, v)
+        if k == "scales":          # iterable of scale indices -> scale_mask
+            for i in v:
+                p.scale_mask[i >> 6] |= 1 << (i & 63)
+        else:
+            setattr(p, k, v)
     return p
 
 
@@ -250,6 +260,7 @@ class DetectResult:
     cascade_ms: float
     total_ms: float
     n_cascade_launches: int
+    passes: list = None          # [(stage_begin, stage_end, ms)] per cascade launch
 
     @property
     def match_count(self) -> int:
@@ -269,6 +280,10 @@ class Environment:
         buf = C.create_string_buffer(256)
         _check(load_library().vj_env_device_name(self._h, buf, 256), "vj_env_device_name")
         return buf.value.decode()
+
+    def configure(self, key: str, value) -> None:
+        """Tunables that never change results: 'pass_split' ("4,9,15"), 'blocks_per_cu'."""
+        _check(load_library().vj_env_configure(self._h, key.encode(), str(value).encode()), f"vj_env_configure({key})")
 
     def reserve(self, width: int, height: int, batch: int = 1):
         _check(load_library().vj_env_reserve(self._h, width, height, batch), "vj_env_reserve")
@@ -320,7 +335,9 @@ class Environment:
             return DetectResult(rects, int(k.windows), int(k.stump_evals), int(k.gather_bytes),
                                 [int(v) for v in k.stage_entered[:cascade.info.n_stages]],
                                 float(t.integral_ms), float(t.cascade_ms), float(t.total_ms),
-                                int(t.n_cascade_launches))
+                                int(t.n_cascade_launches),
+                                [(int(t.pass_stage_begin[i]), int(t.pass_stage_end[i]), float(t.pass_ms[i]))
+                                 for i in range(min(int(t.n_cascade_launches), VJ_MAX_PASSES))])
         finally:
             lib.vj_result_free(C.byref(res))
 

@@ -107,7 +107,7 @@ constexpr int BAND_ROWS = 8;
 
 // Launch wrappers (defined in vj_kernels.hip); stream is a hipStream_t.
 int launch_integral(const IntegralArgs& a, void* stream);
-int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool last, bool count, int n_blocks,
-                        void* stream);
+int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool last, bool count, bool general,
+                        int n_blocks, void* stream);
 
 }  // namespace vj

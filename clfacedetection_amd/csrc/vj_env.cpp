@@ -64,7 +64,8 @@ struct Plan {
     uint64_t windows_per_frame = 0;
     uint32_t frame_elems = 0;
     uint32_t max_reach_elems = 0;  // furthest element a window origin + feature corner touches
-    bool trees = false;
+    bool trees = false;    // some tree has more than one node
+    bool general = false;  // stage tree (not a linear chain of stages)
     StageProgram prog;
     // device copies
     DevBuf d_table, d_scales, d_stages, d_units;
@@ -79,6 +80,7 @@ struct vj_env {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t pass_ev[VJ_MAX_PASSES + 1] = {};
     char name[256] = "";
     int n_cu = 0;
     // image buffers
@@ -88,7 +90,7 @@ struct vj_env {
     uint32_t det_cap = 0;
     void* h_pinned = nullptr;  // small pinned staging for counts
     size_t h_pinned_bytes = 0;
-    typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint32_t> PlanKey;
+    typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<Plan>> plans;
     // tunables (env vars, read once)
     int blocks_per_cu = 8;
@@ -135,6 +137,7 @@ static std::vector<uint32_t> default_pass_bounds(const vj_cascade& c, const Stag
         }
     }
     b.push_back(n);
+    while (b.size() > (size_t)VJ_MAX_PASSES + 1) b.erase(b.end() - 2);  // at most VJ_MAX_PASSES launches
     return b;
 }
 
@@ -150,8 +153,11 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         const bool linear = pl->prog.on_fail[s] == STAGE_REJECT &&
                             (pl->prog.on_pass[s] == (int)s + 1 ||
                              (pl->prog.on_pass[s] == STAGE_ACCEPT && s + 1 == c.stages.size()));
-        if (!linear) {
-            set_error("stage-tree cascades (stage %zu has a sibling branch) are not supported yet", s);
+        if (!linear) pl->general = true;
+        // the single in-order sweep of the general path needs successors to lie ahead
+        if ((pl->prog.on_pass[s] >= 0 && pl->prog.on_pass[s] <= (int)s) ||
+            (pl->prog.on_fail[s] >= 0 && pl->prog.on_fail[s] <= (int)s)) {
+            set_error("stage %zu links backwards; unsupported stage tree", s);
             return VJ_ERR_UNSUPPORTED;
         }
     }
@@ -163,6 +169,10 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     std::vector<NodeRec> table;
     for (const vj_scale_info& si : pl->scales_all) {
         if (!si.accepted || si.nx <= 0 || si.ny <= 0) continue;
+        if ((p.scale_mask[0] | p.scale_mask[1]) != 0) {  // scale subset (multi-GPU sharding of one frame)
+            const int k = si.scale_idx;
+            if (k >= 128 || !((p.scale_mask[k >> 6] >> (k & 63)) & 1ull)) continue;
+        }
         if (pl->scales.size() >= (size_t)MAX_SCALES) {
             set_error("more than %d scales", MAX_SCALES);
             return VJ_ERR_LIMIT;
@@ -217,6 +227,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         pl->stages.push_back(sd);
     }
     pl->pass_bounds = default_pass_bounds(c, pl->prog, e->split_override);
+    if (pl->general) pl->pass_bounds = {0u, (uint32_t)c.stages.size()};  // one pass (see run_stages_general)
 
     int rc;
     if ((rc = pl->d_table.ensure(std::max<size_t>(table.size(), 1) * sizeof(NodeRec)))) return rc;
@@ -253,7 +264,8 @@ static int layout_queues(Plan* pl, int frames, uint64_t* total_entries) {
 }
 
 static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, Plan** out) {
-    vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), 0u);
+    vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
+                        p.scale_mask[1]);
     auto it = e->plans.find(key);
     if (it != e->plans.end()) {
         *out = it->second.get();
@@ -437,7 +449,8 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 ca.q_out_count = d_qcount[outq];
                 if (ps >= 2)  // the out-queue of pass ps was the in-queue of pass ps-1: reset its counts
                     HIP_TRY(hipMemsetAsync(d_qcount[outq], 0, MAX_SCALES * sizeof(uint32_t), e->stream));
-                int hrc = launch_cascade_pass(ca, ps == 0, pl->trees, last, count, n_blocks, e->stream);
+                if (ps < VJ_MAX_PASSES) HIP_TRY(hipEventRecord(e->pass_ev[ps], e->stream));
+                int hrc = launch_cascade_pass(ca, ps == 0, pl->trees, last, count, pl->general, n_blocks, e->stream);
                 if (hrc) {
                     set_error("cascade launch failed: %s", hipGetErrorString((hipError_t)hrc));
                     return VJ_ERR_HIP;
@@ -445,6 +458,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 ++launches;
             }
         }
+        if (n_pass <= VJ_MAX_PASSES && launches) HIP_TRY(hipEventRecord(e->pass_ev[n_pass], e->stream));
         HIP_TRY(hipEventRecord(e->ev[3], e->stream));
         // read back the counters block
         HIP_TRY(hipMemcpyAsync(e->h_pinned, e->d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
@@ -464,7 +478,15 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         if (attempt == 0) tm->integral_ms += ms_i;
         tm->cascade_ms += ms_c;
         tm->total_ms += ms_t;
-        tm->n_cascade_launches += launches;
+        if (launches && n_pass <= VJ_MAX_PASSES)
+            for (size_t ps = 0; ps < n_pass; ++ps) {
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e->pass_ev[ps], e->pass_ev[ps + 1]));
+                tm->pass_ms[ps] += ms;
+                tm->pass_stage_begin[ps] = (int32_t)pl->pass_bounds[ps];
+                tm->pass_stage_end[ps] = (int32_t)pl->pass_bounds[ps + 1];
+            }
+        tm->n_cascade_launches = std::max(tm->n_cascade_launches, launches);
         if (count) {
             const unsigned long long* se =
                 (const unsigned long long*)((const uint32_t*)e->h_pinned + 2 * MAX_SCALES + 2);
@@ -486,6 +508,8 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
 }
 
 }  // namespace vj
+
+static void drop_plans(vj_env* e);
 
 extern "C" {
 
@@ -516,6 +540,7 @@ int vj_env_create(int device_index, vj_env** out) {
     e->n_cu = prop.multiProcessorCount;
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (auto& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
+    for (auto& ev : e->pass_ev) HIP_TRY(hipEventCreate(&ev));
     e->h_pinned_bytes = 4096;
     HIP_TRY(hipHostMalloc(&e->h_pinned, e->h_pinned_bytes, hipHostMallocDefault));
     if (const char* s = getenv("VJ_BLOCKS_PER_CU")) e->blocks_per_cu = std::max(1, atoi(s));
@@ -536,17 +561,14 @@ void vj_env_destroy(vj_env* e) {
     if (!e) return;
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
-    for (auto& kv : e->plans) {
-        kv.second->d_table.release();
-        kv.second->d_scales.release();
-        kv.second->d_stages.release();
-        kv.second->d_units.release();
-    }
+    drop_plans(e);
     for (DevBuf* b : {&e->d_gray, &e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_q[0],
                       &e->d_q[1], &e->d_counts, &e->d_det})
         b->release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     for (auto& ev : e->ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->pass_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
@@ -556,6 +578,49 @@ int vj_env_device_name(const vj_env* e, char* buf, size_t cap) {
     if (!e || !buf || cap == 0) return VJ_ERR_ARG;
     snprintf(buf, cap, "%s, %d CUs", e->name, e->n_cu);
     return VJ_OK;
+}
+
+static void drop_plans(vj_env* e) {
+    for (auto& kv : e->plans) {
+        kv.second->d_table.release();
+        kv.second->d_scales.release();
+        kv.second->d_stages.release();
+        kv.second->d_units.release();
+    }
+    e->plans.clear();
+}
+
+int vj_env_configure(vj_env* e, const char* key, const char* value) {
+    if (!e || !key || !value) return VJ_ERR_ARG;
+    HIP_TRY(hipSetDevice(e->device));
+    if (strcmp(key, "pass_split") == 0) {
+        std::vector<int> v;
+        for (const char* q = value; *q;) {
+            char* endp;
+            long x = strtol(q, &endp, 10);
+            if (endp == q) {
+                set_error("pass_split: expected comma-separated integers, got '%s'", value);
+                return VJ_ERR_ARG;
+            }
+            v.push_back((int)x);
+            q = *endp ? endp + 1 : endp;
+        }
+        e->split_override = v;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);  // pass bounds are part of a plan
+        return VJ_OK;
+    }
+    if (strcmp(key, "blocks_per_cu") == 0) {
+        const int v = atoi(value);
+        if (v < 1 || v > 16) {
+            set_error("blocks_per_cu must be in [1,16]");
+            return VJ_ERR_ARG;
+        }
+        e->blocks_per_cu = v;
+        return VJ_OK;
+    }
+    set_error("unknown option '%s'", key);
+    return VJ_ERR_ARG;
 }
 
 int vj_env_reserve(vj_env* e, int max_w, int max_h, int max_batch) {

@@ -364,9 +364,64 @@ __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t i
     }
 }
 
-template <bool FROM_GRID, bool TREES, bool LAST, bool COUNT>
+
+// Stage-tree cascades (e.g. frontalface_alt_tree: stage 4 has two child chains): a
+// window's next stage depends on whether it passed (on_pass) or failed (on_fail), so
+// every queued window carries its target stage.  Stages are visited once, in index
+// order (successors always have larger indices); at stage s only the lanes whose
+// target is s evaluate, the others ride along.  Whole cascade in one pass.
+template <bool TREES, bool COUNT>
+__device__ __forceinline__ void run_stages_general(const CascadeArgs& a, rsrc_t img, QEntry* q, int32_t* tgt,
+                                                   uint32_t n, uint32_t scale_slot, uint32_t table_first,
+                                                   uint32_t lane) {
+    kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + table_first;
+    kptr<StageDev> stages = as_k(a.stages);
+    for (uint32_t i = lane; i < n; i += 64u) tgt[i] = (int32_t)a.stage_begin;
+    __builtin_amdgcn_wave_barrier();
+    for (uint32_t s = a.stage_begin; s < a.stage_end && n != 0u; ++s) {
+        const uint32_t first_node = stages[s].first_node;
+        const uint32_t n_nodes = stages[s].n_nodes;
+        const float threshold = stages[s].threshold;
+        const int32_t on_pass = stages[s].on_pass, on_fail = stages[s].on_fail;
+        kptr<NodeRecDev> tab = table + first_node;
+        uint32_t m = 0, entered = 0;
+        for (uint32_t base = 0; base < n; base += 64u) {
+            const uint32_t i = base + lane;
+            const bool act = i < n;
+            const QEntry e = q[act ? i : 0u];
+            int32_t t = tgt[act ? i : 0u];
+            const bool here = act && t == (int32_t)s;
+            if (here) t = (stage_sum_of<TREES>(img, tab, n_nodes, e.off, e.var) >= threshold) ? on_pass : on_fail;
+            const bool keep = act && t >= 0;
+            const unsigned long long acc_mask = __ballot(act && t == -1);  // accepted: falls off the tree's end
+            if (acc_mask != 0ull) {
+                const uint32_t cnt = (uint32_t)__popcll(acc_mask);
+                uint32_t g = 0;
+                if (lane == 0) g = atomicAdd(a.det_count, cnt);
+                g = __builtin_amdgcn_readfirstlane(g);
+                const uint32_t pos = g + mbcnt(acc_mask);
+                if (act && t == -1 && pos < a.det_cap) a.det[pos] = DetEntry{e.off, scale_slot};
+            }
+            if (COUNT) entered += (uint32_t)__popcll(__ballot(here));
+            const unsigned long long mask = __ballot(keep);
+            __builtin_amdgcn_wave_barrier();
+            if (keep) {
+                const uint32_t pos = m + mbcnt(mask);
+                q[pos] = e;
+                tgt[pos] = t;
+            }
+            m += (uint32_t)__popcll(mask);
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (COUNT && lane == 0 && entered != 0u) atomicAdd(a.stage_entered + s, (unsigned long long)entered);
+        n = m;
+    }
+}
+
+template <bool FROM_GRID, bool TREES, bool LAST, bool COUNT, bool GENERAL>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs a) {
     __shared__ QEntry lds_q[WAVES_PER_BLOCK * UNIT_WINDOWS];
+    __shared__ int32_t lds_tgt[GENERAL ? WAVES_PER_BLOCK * UNIT_WINDOWS : 1];
     const uint32_t lane = lane_id();
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     QEntry* q = lds_q + wib * UNIT_WINDOWS;
@@ -410,8 +465,12 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            run_stages_linear<TREES, LAST, COUNT>(a, img, q, count, slot, scales[slot].table_first,
-                                                  scales[slot].q_base, lane);
+            if (GENERAL)
+                run_stages_general<TREES, COUNT>(a, img, q, lds_tgt + wib * UNIT_WINDOWS, count, slot,
+                                                 scales[slot].table_first, lane);
+            else
+                run_stages_linear<TREES, LAST, COUNT>(a, img, q, count, slot, scales[slot].table_first,
+                                                      scales[slot].q_base, lane);
             __builtin_amdgcn_wave_barrier();
         }
     } else {
@@ -441,18 +500,29 @@ template <bool FROM_GRID, bool TREES>
 static void launch_variant(const CascadeArgs& a, bool last, bool count, int n_blocks, hipStream_t stream) {
     dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
     if (last) {
-        if (count) hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, true>), g, b, 0, stream, a);
-        else       hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, false>), g, b, 0, stream, a);
+        if (count) hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, true, false>), g, b, 0, stream, a);
+        else       hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, false, false>), g, b, 0, stream, a);
     } else {
-        if (count) hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, false, true>), g, b, 0, stream, a);
-        else       hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, false, false>), g, b, 0, stream, a);
+        if (count) hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, false, true, false>), g, b, 0, stream, a);
+        else       hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, false, false, false>), g, b, 0, stream, a);
     }
 }
 
-int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool last, bool count, int n_blocks,
-                        void* stream_) {
+template <bool TREES>
+static void launch_general(const CascadeArgs& a, bool count, int n_blocks, hipStream_t stream) {
+    dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
+    if (count) hipLaunchKernelGGL((cascade_pass<true, TREES, true, true, true>), g, b, 0, stream, a);
+    else       hipLaunchKernelGGL((cascade_pass<true, TREES, true, false, true>), g, b, 0, stream, a);
+}
+
+int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool last, bool count, bool general,
+                        int n_blocks, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (from_grid) {
+    if (general) {  // stage-tree cascade: the whole cascade in one first-and-last pass
+        if (!from_grid || !last) return (int)hipErrorInvalidValue;
+        if (trees) launch_general<true>(a, count, n_blocks, stream);
+        else       launch_general<false>(a, count, n_blocks, stream);
+    } else if (from_grid) {
         if (trees) launch_variant<true, true>(a, last, count, n_blocks, stream);
         else       launch_variant<true, false>(a, last, count, n_blocks, stream);
     } else {

@@ -110,8 +110,11 @@ typedef struct vj_params {
     float    scale_factor;     /* reference hard-codes 1.1f (clod.cpp:1184)     */
     uint32_t min_neighbors;    /* 0 = raw candidates (the parity contract)      */
     uint32_t flags;
+    uint64_t scale_mask[2];    /* bit k set = evaluate scale index k (k < 128); both
+                                  words 0 = every scale.  Shards one frame's scales
+                                  across GPUs; the reference has no counterpart.   */
 } vj_params;
-void vj_params_default(vj_params* p);   /* {0,0,0,0,1.1f,0,0} */
+void vj_params_default(vj_params* p);   /* {0,0,0,0,1.1f,0,0,{0,0}} */
 
 /* ------------------------------------------------------ host scale planning */
 /* setupScale + scale enumeration (clod.cpp:371-415, 1198-1204). */
@@ -145,6 +148,10 @@ void vj_env_destroy(vj_env* e);
  * pre-size device buffers; optional — vj_detect grows them on demand.          */
 int  vj_env_reserve(vj_env* e, int max_w, int max_h, int max_batch);
 int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
+/* Tunables (results never depend on them): "pass_split" = comma-separated stage
+ * indices at which the cascade is cut into separate launches ("" = default),
+ * "blocks_per_cu" = persistent workgroups per CU.                               */
+int  vj_env_configure(vj_env* e, const char* key, const char* value);
 
 /* --------------------------------------------------------------- integral */
 /* clifIntegral (clif.h:63-66, clif.cpp:273-285 → cvIntegral layout):
@@ -176,11 +183,15 @@ typedef struct vj_counters {
     uint64_t stage_entered[VJ_MAX_STAGES]; /* windows entering each stage       */
 } vj_counters;
 
+#define VJ_MAX_PASSES 8
 typedef struct vj_timing {     /* HIP-event times of the last vj_detect, ms     */
-    float integral_ms;
+    float integral_ms;         /* the three integral launches                   */
     float cascade_ms;          /* all cascade passes                            */
     float total_ms;            /* first kernel start → last kernel end          */
     int32_t n_cascade_launches;
+    float pass_ms[VJ_MAX_PASSES];            /* each cascade launch             */
+    int32_t pass_stage_begin[VJ_MAX_PASSES]; /* stages [begin, end) it ran      */
+    int32_t pass_stage_end[VJ_MAX_PASSES];
 } vj_timing;
 
 typedef struct vj_result {

@@ -1,0 +1,95 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard a batch (by frames) and a
+single frame (by scales), all-gather the detections and must reproduce the
+single-process result.  The per-rank detector here is the oracle (tests may use it);
+on the GPU box bench.py runs the same sharding code around the HIP path."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+from clfacedetection_amd import multigpu
+
+
+def test_shard_frames_covers_everything():
+    for n in (0, 1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            got = [i for r in range(world) for i in multigpu.shard_frames(n, r, world)]
+            assert got == list(range(n))
+            sizes = [len(multigpu.shard_frames(n, r, world)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_shard_scales_lpt_balance(oracle, cascades):
+    _, a = cascades("frontalface_alt")
+    counts = [s.nx * s.ny if s.accepted else 0 for s in oracle.plan_scales(a, 1920, 1080)]
+    for world in (2, 4, 8):
+        parts = [multigpu.shard_scales(counts, r, world) for r in range(world)]
+        assert sorted(k for p in parts for k in p) == list(range(len(counts)))
+        loads = [sum(counts[k] for k in p) for p in parts]
+        assert max(loads) <= sum(counts) / world + max(counts)        # LPT bound
+    assert multigpu.plan(64, counts, 3, 8) == (list(range(24, 32)), None)
+    frames, scales = multigpu.plan(1, counts, 1, 2)
+    assert frames == [0] and scales is not None
+
+
+def _worker(rank, world, port, mode, q):
+    import sys
+    import torch.distributed as dist
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    sys.path.insert(0, os.path.join(root, "tests"))
+    from clfacedetection_amd import synth
+    from clfacedetection_amd.api import DATA_DIR, RECT_DTYPE
+    from oracle.oracle import Oracle, load_vjc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = Oracle()
+    a = load_vjc(os.path.join(DATA_DIR, "haarcascade_frontalface_alt.vjc"))
+    H, W = 200, 260
+    n_frames = 5 if mode == "frames" else 1
+    frames = synth.batch(n_frames, H, W, seed0=500, kinds=("noise",))
+    counts = [s.nx * s.ny if s.accepted else 0 for s in o.plan_scales(a, W, H)]
+    my_frames, my_scales = multigpu.plan(n_frames, counts, rank, world)
+    rows = []
+    for f in my_frames:
+        r, _ = o.detect(a, frames[f])
+        for d in r:
+            if my_scales is None or int(d["scale_idx"]) in my_scales:
+                rows.append((d["x"], d["y"], d["w"], d["h"], 0.0, f, d["scale_idx"]))
+    mine = np.array(rows, RECT_DTYPE) if rows else np.zeros(0, RECT_DTYPE)
+    allr = multigpu.allgather_rects(mine)
+    q.put((rank, allr.tolist(), len(mine)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["frames", "scales"])
+def test_two_ranks_reproduce_single_process(oracle, cascades, mode):
+    from clfacedetection_amd import synth
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, mode, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=180) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    _, a = cascades("frontalface_alt")
+    n_frames = 5 if mode == "frames" else 1
+    frames = synth.batch(n_frames, 200, 260, seed0=500, kinds=("noise",))
+    want = []
+    for f in range(n_frames):
+        r, _ = oracle.detect(a, frames[f])
+        want += [(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), f, int(d["scale_idx"])) for d in r]
+    assert len(want) > 0
+    for rank, allr, n_mine in got:
+        assert [(x, y, w, h, fr, sc) for (x, y, w, h, _, fr, sc) in allr] == want
+    assert sum(g[2] for g in got) == len(want)      # shards are disjoint
