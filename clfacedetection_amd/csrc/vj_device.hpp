@@ -15,13 +15,26 @@ struct ScaleDev {
     uint32_t e_dw;         // equ_rect width in elements
     uint32_t e_dh;         // equ_rect height * stride in elements
     float    area;         // (float)scaled_window_area
-    uint32_t table_first;  // first NodeRec of this scale in the table
+    uint32_t table_first;  // first NodeRec of this scale in the table (image-stride offsets)
     uint32_t q_base;       // first entry of this scale's segment in the survivor queues
     uint32_t q_cap;        // capacity of that segment (= nwin * frames in flight)
     uint32_t scale_idx;    // k of s_k (for the detection record)
-    uint32_t pad[5];
+    uint32_t ny;           // window grid rows
+    // LDS-tile path (tile_rw == 0: this scale runs on the global-gather path)
+    uint32_t tile_rw;      // != 0: this scale's first pass runs on the LDS-tile kernel
+    uint32_t tile_pitch;   // dwords per row of the LDS image tile
+    uint32_t tile_rows;    // rows of the LDS image tile
+    uint32_t tile_table_first;  // NodeRec table built with stride = tile_pitch
+    uint32_t te_lt;        // equ_rect left-top in tile-pitch elements
+    uint32_t te_dh;        // equ_rect height * tile_pitch
+    uint32_t tiles_x;      // tiles per grid row
+    uint32_t tile_tw;      // windows per tile row
+    uint32_t tile_th;      // window rows per tile (tile_tw * tile_th <= TILE_WAVES * TILE_WAVE_CAP)
+    uint32_t reserved0;
+    uint32_t tile_class;   // LDS size class of the tile launch
+    uint32_t pad[9];
 };
-static_assert(sizeof(ScaleDev) == 64, "ScaleDev is 64 bytes");
+static_assert(sizeof(ScaleDev) == 128, "ScaleDev is 128 bytes");
 
 // One cascade stage with its resolved successors (tempcv.cpp:834-861 flattened).
 struct StageDev {
@@ -31,7 +44,8 @@ struct StageDev {
     int32_t  on_pass;      // next stage, or -1 accept
     int32_t  on_fail;      // next stage, or -2 reject
     uint32_t n_trees;
-    uint32_t pad[2];
+    uint32_t order;        // stage-tree sweep: the i-th record holds the i-th stage to visit (topological)
+    uint32_t pad;
 };
 static_assert(sizeof(StageDev) == 32, "StageDev is 32 bytes");
 
@@ -61,6 +75,11 @@ struct DetEntry {
 constexpr int UNIT_WINDOWS = 512;   // windows per wave-unit == per-wave LDS queue capacity
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MAX_SCALES = 128;
+constexpr int MAX_PASSES = 8;         // == VJ_MAX_PASSES
+constexpr int TILE_WAVES = 8;        // waves per workgroup of the LDS-tile kernel
+constexpr int TILE_W = 64;           // windows per tile row (= lanes of a wave)
+constexpr int TILE_WAVE_CAP = 256;    // windows (= LDS queue entries) per wave of the tile kernel
+constexpr int TILE_CLASSES = 3;       // LDS size classes, one launch each
 
 struct CascadeArgs {
     const uint32_t* sum;        // batch sum images, frame f at f * frame_elems
@@ -68,8 +87,11 @@ struct CascadeArgs {
     const uint32_t* table;      // NodeRec[] viewed as dwords (16 per node)
     const ScaleDev* scales;
     const StageDev* stages;
-    const UnitDev*  units;      // first-pass units of ONE frame
+    const UnitDev*  units;      // first-pass units of ONE frame (global-gather scales)
     uint32_t n_units;           // units per frame
+    const UnitDev*  tile_units; // first-pass tiles of ONE frame (LDS-tile scales): first = ix0 | iy0 << 16
+    uint32_t n_tile_units;
+    uint32_t tile_lds_bytes;    // dynamic LDS of the tile kernel
     uint32_t n_frames;
     uint32_t n_scales;
     uint32_t frame_elems;       // elements per frame in sum / sqsum
@@ -81,6 +103,15 @@ struct CascadeArgs {
     const uint32_t* q_in_count; // per-scale entry counts of q_in
     QEntry*   q_out;            // survivor queue written by this pass (not the last)
     uint32_t* q_out_count;
+    // Tile launches: one survivor queue per pass boundary.  A wave sweeps the cascade one
+    // pass segment at a time and leaves at boundary p — appending to queue p — as soon as
+    // fewer than tile_min_lanes windows survive (or the boundary is >= tile_end).
+    uint32_t  n_pass;                       // segments: [pass_begin[p], pass_begin[p+1])
+    uint32_t  pass_begin[MAX_PASSES + 1];
+    QEntry*   q_pass[MAX_PASSES];           // q_pass[p]: windows waiting to enter segment p (p >= 1)
+    uint32_t* q_pass_count[MAX_PASSES];
+    uint32_t  tile_end;                     // deepest stage a tile launch may enter
+    uint32_t  tile_min_lanes;
     DetEntry* det;              // detections (last pass)
     uint32_t* det_count;
     uint32_t  det_cap;
@@ -109,5 +140,6 @@ constexpr int BAND_ROWS = 8;
 int launch_integral(const IntegralArgs& a, void* stream);
 int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool last, bool count, bool general,
                         int n_blocks, void* stream);
+int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, int n_blocks, void* stream);
 
 }  // namespace vj

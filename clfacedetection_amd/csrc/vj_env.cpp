@@ -59,16 +59,21 @@ struct Plan {
     std::vector<ScaleDev> scales;            // accepted scales with nwin > 0
     std::vector<vj_scale_info> scales_info;  // same order as `scales`
     std::vector<StageDev> stages;
-    std::vector<UnitDev> units;              // first-pass units of one frame
+    std::vector<UnitDev> units;              // first-pass units of one frame (global-gather scales)
+    std::vector<UnitDev> tile_units;         // first-pass tiles of one frame, grouped by LDS class
+    uint32_t class_first[TILE_CLASSES + 1] = {};  // tile_units range of each class
+    uint32_t class_lds[TILE_CLASSES] = {};        // dynamic LDS bytes of each class launch
+    uint32_t tile_end = 0;                        // stage at which the tile launches stop
     std::vector<uint32_t> pass_bounds;       // stage indices: pass p runs [b[p], b[p+1])
     uint64_t windows_per_frame = 0;
     uint32_t frame_elems = 0;
     uint32_t max_reach_elems = 0;  // furthest element a window origin + feature corner touches
     bool trees = false;    // some tree has more than one node
     bool general = false;  // stage tree (not a linear chain of stages)
+    uint32_t n_order = 0;  // stages reachable from stage 0, in StageDev::order
     StageProgram prog;
     // device copies
-    DevBuf d_table, d_scales, d_stages, d_units;
+    DevBuf d_table, d_scales, d_stages, d_units, d_tile_units;
     int frames_q = 0;  // frames the ScaleDev.q_base/q_cap currently describe
 };
 
@@ -86,7 +91,7 @@ struct vj_env {
     // image buffers
     DevBuf d_gray, d_sum, d_sqsum, d_band_sum, d_band_sq, d_band_sqp;
     // survivor queues + counters + detections
-    DevBuf d_q[2], d_counts, d_det;
+    DevBuf d_q[MAX_PASSES], d_counts, d_det;   // d_q[p]: windows waiting to enter pass p (p >= 1)
     uint32_t det_cap = 0;
     void* h_pinned = nullptr;  // small pinned staging for counts
     size_t h_pinned_bytes = 0;
@@ -94,6 +99,10 @@ struct vj_env {
     std::map<PlanKey, std::unique_ptr<Plan>> plans;
     // tunables (env vars, read once)
     int blocks_per_cu = 8;
+    int tile_class_kb[TILE_CLASSES] = {36, 64, 140};  // image-tile LDS budget per class; all 0 disables the tile path
+    int tile_min_windows = 1024;  // a class is acceptable for a scale when a tile holds at least this many windows
+    int tile_end = 8;             // tile launches never enter a pass that begins at or beyond this stage
+    int tile_min_lanes = 0;       // a tile wave leaves at a pass boundary when fewer windows than this survive
     std::vector<int> split_override;
 };
 
@@ -124,11 +133,12 @@ static std::vector<uint32_t> default_pass_bounds(const vj_cascade& c, const Stag
         for (int v : override_)
             if (v > (int)b.back() && v < (int)n) b.push_back((uint32_t)v);
     } else {
-        // cut after roughly 80, 320 and 1000 cumulative nodes (frontalface_alt: 4 | 9 | 15)
-        const uint32_t cuts[3] = {80, 330, 1000};
+        // cut after roughly 110 and 250 cumulative nodes (frontalface_alt: 5 | 8), measured best
+        // on 1080p batches: [0,5) global first pass, tiles to 8, one re-packed queue pass after
+        const uint32_t cuts[2] = {110, 250};
         uint32_t acc = 0;
         int ci = 0;
-        for (uint32_t s = 0; s < n && ci < 3; ++s) {
+        for (uint32_t s = 0; s < n && ci < 2; ++s) {
             acc += prog.n_nodes[s];
             if (acc >= cuts[ci] && s + 1 < n) {
                 b.push_back(s + 1);
@@ -154,12 +164,40 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                             (pl->prog.on_pass[s] == (int)s + 1 ||
                              (pl->prog.on_pass[s] == STAGE_ACCEPT && s + 1 == c.stages.size()));
         if (!linear) pl->general = true;
-        // the single in-order sweep of the general path needs successors to lie ahead
-        if ((pl->prog.on_pass[s] >= 0 && pl->prog.on_pass[s] <= (int)s) ||
-            (pl->prog.on_fail[s] >= 0 && pl->prog.on_fail[s] <= (int)s)) {
-            set_error("stage %zu links backwards; unsupported stage tree", s);
+    }
+    // Topological order of the pass/fail graph rooted at stage 0 (depth-first, pass edge
+    // first): the general path sweeps the stages once in this order.
+    std::vector<uint32_t> order;
+    {
+        const int nS = (int)c.stages.size();
+        std::vector<int> state(nS, 0);  // 0 unvisited, 1 on stack, 2 done
+        std::vector<uint32_t> post;
+        bool cyclic = false;
+        std::vector<std::pair<int, int>> stack{{0, 0}};
+        state[0] = 1;
+        while (!stack.empty()) {
+            auto& [s, phase] = stack.back();
+            if (phase < 2) {
+                const int nxt = phase == 0 ? pl->prog.on_pass[s] : pl->prog.on_fail[s];
+                ++phase;
+                if (nxt >= 0) {
+                    if (state[nxt] == 1) cyclic = true;
+                    if (state[nxt] == 0) {
+                        state[nxt] = 1;
+                        stack.push_back({nxt, 0});
+                    }
+                }
+            } else {
+                state[s] = 2;
+                post.push_back((uint32_t)s);
+                stack.pop_back();
+            }
+        }
+        if (cyclic) {
+            set_error("stage links form a cycle");
             return VJ_ERR_UNSUPPORTED;
         }
+        order.assign(post.rbegin(), post.rend());  // reverse post-order; unreachable stages are dropped
     }
     pl->scales_all = plan_scales(c, W, H, p);
     pl->frame_elems = frame_elems_for(W, H);
@@ -204,10 +242,62 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         reach += y_max * stride + x_max;
         pl->max_reach_elems = std::max(pl->max_reach_elems, reach);
         pl->windows_per_frame += sd.nwin;
-        // first-pass units: runs of UNIT_WINDOWS consecutive windows
+        sd.ny = (uint32_t)si.ny;
         const uint32_t slot = (uint32_t)pl->scales.size();
-        for (uint32_t f = 0; f < sd.nwin; f += UNIT_WINDOWS)
-            pl->units.push_back(UnitDev{slot, f, std::min<uint32_t>(UNIT_WINDOWS, sd.nwin - f), 0});
+
+        // LDS-tile path: does a 64 x (TILE_WAVES * rw) window tile's footprint fit the budget?
+        uint32_t reach_x = (uint32_t)(si.equ_x + si.equ_w), reach_y = (uint32_t)(si.equ_y + si.equ_h);
+        for (size_t k = 0; k < n_nodes; ++k) {
+            const NodeRec& r = table[sd.table_first + k];
+            const uint32_t dw[3] = {r.dw01 & 0xffffu, r.dw01 >> 16, r.dw2_flags & 0xffffu};
+            for (int q = 0; q < 3; ++q)
+                if (q < 2 || r.w[2] != 0.0f) {
+                    const uint32_t lt = r.lt[q] / 4u;
+                    reach_x = std::max(reach_x, lt % stride + dw[q] / 4u);
+                    reach_y = std::max(reach_y, lt / stride + (r.dh[q] / 4u) / stride);
+                }
+        }
+        if (!pl->general && si.ny < 65536 && si.nx < 65536) {
+            // candidate tile shapes; per class the shape with the most windows that fits wins
+            static const uint32_t kTw[] = {64, 48, 32, 24, 16, 12, 8}, kTh[] = {32, 24, 16, 12, 8, 6, 4};
+            uint32_t best_cls = TILE_CLASSES, best_n = 0, b_tw = 0, b_th = 0, b_pitch = 0, b_rows = 0;
+            for (uint32_t cls = 0; cls < TILE_CLASSES && best_n < (uint32_t)e->tile_min_windows; ++cls) {
+                const uint64_t budget = (uint64_t)e->tile_class_kb[cls] * 1024u;
+                for (uint32_t tw : kTw)
+                    for (uint32_t th : kTh) {
+                        const uint32_t nwt = tw * th;
+                        if (nwt > TILE_WAVES * TILE_WAVE_CAP || nwt < 64 || nwt <= best_n) continue;
+                        const uint32_t pitch =
+                            ((uint32_t)std::ceil((double)(tw - 1) * (double)si.step) + 3u + reach_x) | 1u;  // odd pitch
+                        const uint32_t rows = (uint32_t)std::ceil((double)(th - 1) * (double)si.step) + 3u + reach_y;
+                        if ((uint64_t)pitch * rows * 4u > budget) continue;
+                        // staging a tile must stay far cheaper than gathering its windows from L2
+                        if ((uint64_t)pitch * rows > 600ull * nwt) continue;
+                        best_cls = cls; best_n = nwt; b_tw = tw; b_th = th; b_pitch = pitch; b_rows = rows;
+                    }
+            }
+            if (best_n >= 128) {
+                sd.tile_rw = 1;
+                sd.tile_tw = b_tw;
+                sd.tile_th = b_th;
+                sd.tile_pitch = b_pitch;
+                sd.tile_rows = b_rows;
+                sd.tile_class = best_cls;
+            }
+        }
+        if (sd.tile_rw) {
+            sd.tile_table_first = (uint32_t)table.size();
+            table.resize(table.size() + n_nodes);
+            rc = build_node_table_stride(c, sd.tile_pitch, si, table.data() + sd.tile_table_first);
+            if (rc) return rc;
+            sd.te_lt = (uint32_t)si.equ_y * sd.tile_pitch + (uint32_t)si.equ_x;
+            sd.te_dh = (uint32_t)si.equ_h * sd.tile_pitch;
+            sd.tiles_x = (sd.nx + sd.tile_tw - 1) / sd.tile_tw;
+        } else {
+            // global-gather first pass: runs of UNIT_WINDOWS consecutive windows
+            for (uint32_t f = 0; f < sd.nwin; f += UNIT_WINDOWS)
+                pl->units.push_back(UnitDev{slot, f, std::min<uint32_t>(UNIT_WINDOWS, sd.nwin - f), 0});
+        }
         pl->scales.push_back(sd);
         pl->scales_info.push_back(si);
     }
@@ -224,16 +314,38 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         sd.on_pass = pl->prog.on_pass[s];
         sd.on_fail = pl->prog.on_fail[s];
         sd.n_trees = (uint32_t)c.stages[s].n_trees;
+        sd.order = s < order.size() ? order[s] : 0u;
         pl->stages.push_back(sd);
     }
+    pl->n_order = (uint32_t)order.size();
     pl->pass_bounds = default_pass_bounds(c, pl->prog, e->split_override);
-    if (pl->general) pl->pass_bounds = {0u, (uint32_t)c.stages.size()};  // one pass (see run_stages_general)
+    if (pl->general) pl->pass_bounds = {0u, pl->n_order};  // one pass over StageDev::order (run_stages_general)
+    // tile launches run deeper than the global-gather first pass (LDS gathers are ~10x cheaper)
+    pl->tile_end = std::min<uint32_t>((uint32_t)c.stages.size(), std::max<uint32_t>((uint32_t)e->tile_end, pl->pass_bounds[1]));
+    if (pl->pass_bounds.size() == 2) pl->tile_end = pl->pass_bounds[1];
+    for (uint32_t cls = 0; cls < TILE_CLASSES; ++cls) {
+        pl->class_first[cls] = (uint32_t)pl->tile_units.size();
+        for (uint32_t slot = 0; slot < pl->scales.size(); ++slot) {
+            ScaleDev& sd = pl->scales[slot];
+            if (!sd.tile_rw || sd.tile_class != cls) continue;
+            for (uint32_t iy0 = 0; iy0 < sd.ny; iy0 += sd.tile_th)
+                for (uint32_t ix0 = 0; ix0 < sd.nx; ix0 += sd.tile_tw)
+                    pl->tile_units.push_back(UnitDev{slot, ix0 | (iy0 << 16), 0, 0});
+            pl->class_lds[cls] = std::max(pl->class_lds[cls], sd.tile_pitch * sd.tile_rows * 4u);
+        }
+        if (pl->class_lds[cls]) pl->class_lds[cls] += TILE_WAVES * TILE_WAVE_CAP * (uint32_t)sizeof(QEntry);
+    }
+    pl->class_first[TILE_CLASSES] = (uint32_t)pl->tile_units.size();
 
     int rc;
     if ((rc = pl->d_table.ensure(std::max<size_t>(table.size(), 1) * sizeof(NodeRec)))) return rc;
     if ((rc = pl->d_scales.ensure(std::max<size_t>(pl->scales.size(), 1) * sizeof(ScaleDev)))) return rc;
     if ((rc = pl->d_stages.ensure(pl->stages.size() * sizeof(StageDev)))) return rc;
     if ((rc = pl->d_units.ensure(std::max<size_t>(pl->units.size(), 1) * sizeof(UnitDev)))) return rc;
+    if ((rc = pl->d_tile_units.ensure(std::max<size_t>(pl->tile_units.size(), 1) * sizeof(UnitDev)))) return rc;
+    if (!pl->tile_units.empty())
+        HIP_TRY(hipMemcpy(pl->d_tile_units.p, pl->tile_units.data(), pl->tile_units.size() * sizeof(UnitDev),
+                          hipMemcpyHostToDevice));
     if (!table.empty())
         HIP_TRY(hipMemcpy(pl->d_table.p, table.data(), table.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pl->d_stages.p, pl->stages.data(), pl->stages.size() * sizeof(StageDev), hipMemcpyHostToDevice));
@@ -278,6 +390,7 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
         pl->d_scales.release();
         pl->d_stages.release();
         pl->d_units.release();
+        pl->d_tile_units.release();
         return rc;
     }
     *out = pl.get();
@@ -387,20 +500,20 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
     uint64_t q_entries = 0;
     if ((rc = layout_queues(pl, nf, &q_entries))) return rc;
     const size_t n_pass = pl->pass_bounds.size() - 1;
-    if (n_pass > 1) {
-        if ((rc = e->d_q[0].ensure(std::max<uint64_t>(q_entries, 1) * sizeof(QEntry)))) return rc;
-        if (n_pass > 2 && (rc = e->d_q[1].ensure(std::max<uint64_t>(q_entries, 1) * sizeof(QEntry)))) return rc;
-    }
-    // counters block: [2][MAX_SCALES] queue counts | det_count | pad | stage_entered[VJ_MAX_STAGES] (u64)
-    const size_t counts_bytes = (2 * MAX_SCALES + 2) * sizeof(uint32_t) + VJ_MAX_STAGES * sizeof(uint64_t);
+    for (size_t ps = 1; ps < n_pass; ++ps)
+        if ((rc = e->d_q[ps].ensure(std::max<uint64_t>(q_entries, 1) * sizeof(QEntry)))) return rc;
+    // counters block: [MAX_PASSES][MAX_SCALES] queue counts | det_count | pad | stage_entered[VJ_MAX_STAGES] (u64)
+    const size_t counts_bytes = (MAX_PASSES * MAX_SCALES + 2) * sizeof(uint32_t) + VJ_MAX_STAGES * sizeof(uint64_t);
     if ((rc = e->d_counts.ensure(counts_bytes))) return rc;
     if (e->det_cap == 0) {
         e->det_cap = 1u << 16;
         if ((rc = e->d_det.ensure((size_t)e->det_cap * sizeof(DetEntry)))) return rc;
     }
-    uint32_t* d_qcount[2] = {(uint32_t*)e->d_counts.p, (uint32_t*)e->d_counts.p + MAX_SCALES};
-    uint32_t* d_det_count = (uint32_t*)e->d_counts.p + 2 * MAX_SCALES;
-    unsigned long long* d_stage_entered = (unsigned long long*)((uint32_t*)e->d_counts.p + 2 * MAX_SCALES + 2);
+    uint32_t* d_qcount[MAX_PASSES];
+    for (int ps = 0; ps < MAX_PASSES; ++ps) d_qcount[ps] = (uint32_t*)e->d_counts.p + ps * MAX_SCALES;
+    uint32_t* d_det_count = (uint32_t*)e->d_counts.p + MAX_PASSES * MAX_SCALES;
+    unsigned long long* d_stage_entered =
+        (unsigned long long*)((uint32_t*)e->d_counts.p + MAX_PASSES * MAX_SCALES + 2);
 
     const uint8_t* d_gray;
     size_t gray_frame_bytes;
@@ -425,6 +538,8 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.stages = (const StageDev*)pl->d_stages.p;
         ca.units = (const UnitDev*)pl->d_units.p;
         ca.n_units = (uint32_t)pl->units.size();
+        ca.tile_units = (const UnitDev*)pl->d_tile_units.p;
+        ca.n_tile_units = (uint32_t)pl->tile_units.size();
         ca.n_frames = (uint32_t)nf;
         ca.n_scales = (uint32_t)pl->scales.size();
         ca.frame_elems = pl->frame_elems;
@@ -436,21 +551,45 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.det_cap = e->det_cap;
         ca.signed_mean = (p.flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
         ca.stage_entered = d_stage_entered;
+        ca.n_pass = (uint32_t)n_pass;
+        for (size_t ps = 0; ps <= n_pass; ++ps) ca.pass_begin[ps] = pl->pass_bounds[ps];
+        for (size_t ps = 1; ps < n_pass; ++ps) {
+            ca.q_pass[ps] = (QEntry*)e->d_q[ps].p;
+            ca.q_pass_count[ps] = d_qcount[ps];
+        }
+        ca.tile_end = (uint32_t)e->tile_end;
+        ca.tile_min_lanes = (uint32_t)e->tile_min_lanes;
         int launches = 0;
-        if (ca.n_units > 0) {
+        if (ca.n_units + ca.n_tile_units > 0) {
             for (size_t ps = 0; ps < n_pass; ++ps) {
                 ca.stage_begin = pl->pass_bounds[ps];
                 ca.stage_end = pl->pass_bounds[ps + 1];
                 const bool last = ps + 1 == n_pass;
-                const int in = (int)((ps + 1) & 1), outq = (int)(ps & 1);  // pass 0 writes q[0], pass 1 reads q[0] writes q[1] ...
-                ca.q_in = (const QEntry*)e->d_q[in].p;
-                ca.q_in_count = d_qcount[in];
-                ca.q_out = (QEntry*)e->d_q[outq].p;
-                ca.q_out_count = d_qcount[outq];
-                if (ps >= 2)  // the out-queue of pass ps was the in-queue of pass ps-1: reset its counts
-                    HIP_TRY(hipMemsetAsync(d_qcount[outq], 0, MAX_SCALES * sizeof(uint32_t), e->stream));
+                // pass ps reads queue ps (filled by pass ps-1 and by tile waves that left at
+                // this boundary) and appends its survivors to queue ps+1
+                ca.q_in = (const QEntry*)e->d_q[ps].p;
+                ca.q_in_count = d_qcount[ps];
+                ca.q_out = last ? nullptr : (QEntry*)e->d_q[ps + 1].p;
+                ca.q_out_count = last ? nullptr : d_qcount[ps + 1];
                 if (ps < VJ_MAX_PASSES) HIP_TRY(hipEventRecord(e->pass_ev[ps], e->stream));
-                int hrc = launch_cascade_pass(ca, ps == 0, pl->trees, last, count, pl->general, n_blocks, e->stream);
+                int hrc = 0;
+                if (ps == 0) {
+                    for (uint32_t cls = 0; cls < TILE_CLASSES && !hrc; ++cls) {
+                        const uint32_t n_cls = pl->class_first[cls + 1] - pl->class_first[cls];
+                        if (!n_cls) continue;
+                        CascadeArgs ta = ca;
+                        ta.tile_units = (const UnitDev*)pl->d_tile_units.p + pl->class_first[cls];
+                        ta.n_tile_units = n_cls;
+                        ta.tile_lds_bytes = pl->class_lds[cls];
+                        // workgroups per CU: what the LDS allows (160 KiB per CU), at most 4 x 8 waves
+                        const int per_cu = std::max(1, std::min(4, (int)(160u * 1024u / ta.tile_lds_bytes)));
+                        const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf,
+                                                               (uint64_t)e->n_cu * (uint64_t)per_cu);
+                        hrc = launch_cascade_tile_pass(ta, pl->trees, count, std::max(1, tb), e->stream);
+                    }
+                }
+                if (!hrc && (ps > 0 || ca.n_units > 0))
+                    hrc = launch_cascade_pass(ca, ps == 0, pl->trees, last, count, pl->general, n_blocks, e->stream);
                 if (hrc) {
                     set_error("cascade launch failed: %s", hipGetErrorString((hipError_t)hrc));
                     return VJ_ERR_HIP;
@@ -463,7 +602,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         // read back the counters block
         HIP_TRY(hipMemcpyAsync(e->h_pinned, e->d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        const uint32_t n_det = ((const uint32_t*)e->h_pinned)[2 * MAX_SCALES];
+        const uint32_t n_det = ((const uint32_t*)e->h_pinned)[MAX_PASSES * MAX_SCALES];
         float ms_i = 0, ms_c = 0, ms_t = 0;
         HIP_TRY(hipEventElapsedTime(&ms_i, e->ev[0], e->ev[1]));
         HIP_TRY(hipEventElapsedTime(&ms_c, e->ev[2], e->ev[3]));
@@ -489,7 +628,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         tm->n_cascade_launches = std::max(tm->n_cascade_launches, launches);
         if (count) {
             const unsigned long long* se =
-                (const unsigned long long*)((const uint32_t*)e->h_pinned + 2 * MAX_SCALES + 2);
+                (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * MAX_SCALES + 2);
             for (size_t s = 0; s < pl->stages.size(); ++s) ctr->stage_entered[s] += se[s];
         }
         std::vector<DetEntry> raw(n_det);
@@ -541,7 +680,7 @@ int vj_env_create(int device_index, vj_env** out) {
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (auto& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
     for (auto& ev : e->pass_ev) HIP_TRY(hipEventCreate(&ev));
-    e->h_pinned_bytes = 4096;
+    e->h_pinned_bytes = 8192;
     HIP_TRY(hipHostMalloc(&e->h_pinned, e->h_pinned_bytes, hipHostMallocDefault));
     if (const char* s = getenv("VJ_BLOCKS_PER_CU")) e->blocks_per_cu = std::max(1, atoi(s));
     if (const char* s = getenv("VJ_PASS_SPLIT")) {  // e.g. "4,9,15"
@@ -562,9 +701,10 @@ void vj_env_destroy(vj_env* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     drop_plans(e);
-    for (DevBuf* b : {&e->d_gray, &e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_q[0],
-                      &e->d_q[1], &e->d_counts, &e->d_det})
+    for (DevBuf* b : {&e->d_gray, &e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_counts,
+                      &e->d_det})
         b->release();
+    for (DevBuf& b : e->d_q) b.release();
     if (e->h_pinned) (void)hipHostFree(e->h_pinned);
     for (auto& ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
@@ -586,6 +726,7 @@ static void drop_plans(vj_env* e) {
         kv.second->d_scales.release();
         kv.second->d_stages.release();
         kv.second->d_units.release();
+        kv.second->d_tile_units.release();
     }
     e->plans.clear();
 }
@@ -608,6 +749,36 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         e->split_override = v;
         HIP_TRY(hipStreamSynchronize(e->stream));
         drop_plans(e);  // pass bounds are part of a plan
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_classes_kb") == 0) {  // "36,64,140"; "0,0,0" disables the LDS-tile path
+        int v[TILE_CLASSES] = {0, 0, 0};
+        const char* q = value;
+        for (int i = 0; i < TILE_CLASSES && *q; ++i) {
+            char* endp;
+            v[i] = (int)strtol(q, &endp, 10);
+            if (endp == q || v[i] < 0 || v[i] > 140) {
+                set_error("tile_classes_kb: expected up to %d values in [0,140]", TILE_CLASSES);
+                return VJ_ERR_ARG;
+            }
+            q = *endp ? endp + 1 : endp;
+        }
+        for (int i = 0; i < TILE_CLASSES; ++i) e->tile_class_kb[i] = v[i];
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_min_windows") == 0 || strcmp(key, "tile_end") == 0 || strcmp(key, "tile_min_lanes") == 0) {
+        const int v = atoi(value);
+        if (v < 0 || v > 4096) {
+            set_error("%s out of range", key);
+            return VJ_ERR_ARG;
+        }
+        (strcmp(key, "tile_min_windows") == 0 ? e->tile_min_windows
+         : strcmp(key, "tile_end") == 0       ? e->tile_end
+                                              : e->tile_min_lanes) = v;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
         return VJ_OK;
     }
     if (strcmp(key, "blocks_per_cu") == 0) {

@@ -235,24 +235,40 @@ __device__ __forceinline__ float window_variance(rsrc_t sum_f, rsrc_t sq_f, uint
     return variance >= 0.0f ? sqrtf(variance) : 1.0f;
 }
 
+// Where a window's corner values come from.  Both sources take the lane's window
+// offset (bytes) plus a wave-uniform corner offset (bytes).
+//  * GlobalImg: the batch sum image in HBM/L2 through buffer loads (no VALU address
+//    arithmetic; every lane is its own request in the texture-address unit, which is
+//    what bounds this path: ~40-64 cycles per wave-load, measured).
+//  * LdsImg: a tile of the sum image staged in LDS (2-4 cycles per wave-load).
+struct GlobalImg {
+    rsrc_t r;
+    __device__ __forceinline__ uint32_t ld(uint32_t lane_off, uint32_t uni_off) const { return ld_u32(r, lane_off, uni_off); }
+};
+struct LdsImg {
+    const char* base;  // LDS
+    __device__ __forceinline__ uint32_t ld(uint32_t lane_off, uint32_t uni_off) const {
+        return *reinterpret_cast<const uint32_t*>(base + (lane_off + uni_off));
+    }
+};
+
 // The weighted rectangle sums of one node (clod.cl:60-76) for the lane's window.
-__device__ __forceinline__ float node_rect_sum(rsrc_t img, const NodeRecDev& r, uint32_t off) {
+template <typename Img>
+__device__ __forceinline__ float node_rect_sum(const Img& img, const NodeRecDev& r, uint32_t off) {
     const uint32_t lt0 = r[0], lt1 = r[1], lt2 = r[2];
     const uint32_t dh0 = r[3], dh1 = r[4], dh2 = r[5];
     const uint32_t dw0 = r[6] & 0xffffu, dw1 = r[6] >> 16, dw2 = r[7] & 0xffffu;
     const float w0 = __uint_as_float(r[8]), w1 = __uint_as_float(r[9]), w2 = __uint_as_float(r[10]);
     // u32 wrap-around on the four corners, one cast, one multiply per rectangle
-    const uint32_t r0 = ld_u32(img, off, lt0) - ld_u32(img, off, lt0 + dw0) - ld_u32(img, off, lt0 + dh0) +
-                        ld_u32(img, off, lt0 + dh0 + dw0);
-    const uint32_t r1 = ld_u32(img, off, lt1) - ld_u32(img, off, lt1 + dw1) - ld_u32(img, off, lt1 + dh1) +
-                        ld_u32(img, off, lt1 + dh1 + dw1);
+    const uint32_t r0 = img.ld(off, lt0) - img.ld(off, lt0 + dw0) - img.ld(off, lt0 + dh0) + img.ld(off, lt0 + dh0 + dw0);
+    const uint32_t r1 = img.ld(off, lt1) - img.ld(off, lt1 + dw1) - img.ld(off, lt1 + dh1) + img.ld(off, lt1 + dh1 + dw1);
     // rect_sum = 0; rect_sum += t0; — the leading "0 +" only maps -0 to +0, which no
     // comparison or later sum can observe, so it is elided.
     float rect_sum = (float)r0 * w0;
     rect_sum += (float)r1 * w1;
     if (w2 != 0.0f) {  // uniform branch (clod.cl:70)
-        const uint32_t r2 = ld_u32(img, off, lt2) - ld_u32(img, off, lt2 + dw2) - ld_u32(img, off, lt2 + dh2) +
-                            ld_u32(img, off, lt2 + dh2 + dw2);
+        const uint32_t r2 =
+            img.ld(off, lt2) - img.ld(off, lt2 + dw2) - img.ld(off, lt2 + dh2) + img.ld(off, lt2 + dh2 + dw2);
         rect_sum += (float)r2 * w2;
     }
     return rect_sum;
@@ -260,15 +276,19 @@ __device__ __forceinline__ float node_rect_sum(rsrc_t img, const NodeRecDev& r, 
 
 // One stump-based stage on one window (clod.cl:49-82).  `tab` points at the stage's
 // first node record of the wave's scale; every table value is wave-uniform.
-__device__ __forceinline__ float stage_sum_stumps(rsrc_t img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
+template <typename Img>
+__device__ __forceinline__ float stage_sum_stumps(const Img& img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
                                                   float var) {
     float stage_sum = 0.0f;
+    NodeRecDev r = tab[0];
     for (uint32_t j = 0; j < n_nodes; ++j) {
-        const NodeRecDev r = tab[j];
+        // fetch the next record while this one is evaluated (scalar loads are long)
+        const NodeRecDev rn = tab[j + 1 < n_nodes ? j + 1 : j];
         const float norm_threshold = __uint_as_float(r[11]) * var;
         const float rect_sum = node_rect_sum(img, r, off);
         // alpha[rect_sum >= norm_threshold]: alpha[0] = left_val, alpha[1] = right_val
         stage_sum += (rect_sum >= norm_threshold) ? __uint_as_float(r[13]) : __uint_as_float(r[12]);
+        r = rn;
     }
     return stage_sum;
 }
@@ -277,7 +297,8 @@ __device__ __forceinline__ float stage_sum_stumps(rsrc_t img, kptr<NodeRecDev> t
 // f32 arithmetic.  Nodes of a tree are stored consecutively and a child always has a
 // larger index than its parent, so a tree is evaluated by visiting its records in
 // order, each with the lanes whose walk currently sits on it; the table stays uniform.
-__device__ __forceinline__ float stage_sum_trees(rsrc_t img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
+template <typename Img>
+__device__ __forceinline__ float stage_sum_trees(const Img& img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
                                                  float var) {
     float stage_sum = 0.0f;
     uint32_t cur = 0;     // node (inside the current tree) this lane evaluates next
@@ -311,24 +332,22 @@ __device__ __forceinline__ float stage_sum_trees(rsrc_t img, kptr<NodeRecDev> ta
     return stage_sum;
 }
 
-template <bool TREES>
-__device__ __forceinline__ float stage_sum_of(rsrc_t img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
+template <bool TREES, typename Img>
+__device__ __forceinline__ float stage_sum_of(const Img& img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
                                               float var) {
     if (TREES) return stage_sum_trees(img, tab, n_nodes, off, var);
     return stage_sum_stumps(img, tab, n_nodes, off, var);
 }
 
-// Runs stages [a.stage_begin, a.stage_end) over the wave's LDS queue q[0..n) of one
-// scale, compacting survivors in place after every stage, then hands the survivors to
-// the next pass's global queue (or to the detection list).  Linear cascades
-// (on_pass = s + 1, on_fail = reject): every queued window is at the same stage.
-template <bool TREES, bool LAST, bool COUNT>
-__device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t img, QEntry* q, uint32_t n,
-                                                  uint32_t scale_slot, uint32_t table_first, uint32_t q_base,
-                                                  uint32_t lane) {
-    kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + table_first;
+// Compacting stage sweep shared by every pass: runs stages [a.stage_begin, a.stage_end)
+// over the wave's LDS queue q[0..n) (all entries belong to one scale and sit at the same
+// stage — linear cascades), compacting survivors in place after every stage.  Returns
+// the number of survivors left at q[0..).
+template <bool TREES, bool COUNT, typename Img>
+__device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img& img, kptr<NodeRecDev> table,
+                                                 QEntry* q, uint32_t n, uint32_t lane, uint32_t begin, uint32_t end) {
     kptr<StageDev> stages = as_k(a.stages);
-    for (uint32_t s = a.stage_begin; s < a.stage_end && n != 0u; ++s) {
+    for (uint32_t s = begin; s < end && n != 0u; ++s) {
         const uint32_t first_node = stages[s].first_node;
         const uint32_t n_nodes = stages[s].n_nodes;
         const float threshold = stages[s].threshold;
@@ -349,6 +368,18 @@ __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t i
         }
         n = m;
     }
+    return n;
+}
+
+// Global-gather pass body: sweep the stages, then hand the survivors to the next pass's
+// global queue (or to the detection list).
+template <bool TREES, bool LAST, bool COUNT>
+__device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t img_r, QEntry* q, uint32_t n,
+                                                  uint32_t scale_slot, uint32_t table_first, uint32_t q_base,
+                                                  uint32_t lane, uint32_t begin) {
+    kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + table_first;
+    const GlobalImg img{img_r};
+    n = sweep_stages<TREES, COUNT>(a, img, table, q, n, lane, begin, a.stage_end);
     if (n == 0u) return;
     if (LAST) {
         uint32_t g = 0;
@@ -364,21 +395,23 @@ __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t i
     }
 }
 
-
 // Stage-tree cascades (e.g. frontalface_alt_tree: stage 4 has two child chains): a
 // window's next stage depends on whether it passed (on_pass) or failed (on_fail), so
-// every queued window carries its target stage.  Stages are visited once, in index
-// order (successors always have larger indices); at stage s only the lanes whose
-// target is s evaluate, the others ride along.  Whole cascade in one pass.
+// every queued window carries its target stage.  Stages are visited once, in a
+// topological order of the pass/fail graph computed on the host (StageDev::order —
+// e.g. 0..4, chain 5,7,..,39, then chain 6,8,..,46: failing in the first chain jumps
+// BACK to stage 6); at stage s only the lanes whose target is s evaluate, the others
+// ride along.  Whole cascade in one pass.
 template <bool TREES, bool COUNT>
 __device__ __forceinline__ void run_stages_general(const CascadeArgs& a, rsrc_t img, QEntry* q, int32_t* tgt,
                                                    uint32_t n, uint32_t scale_slot, uint32_t table_first,
                                                    uint32_t lane) {
     kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + table_first;
     kptr<StageDev> stages = as_k(a.stages);
-    for (uint32_t i = lane; i < n; i += 64u) tgt[i] = (int32_t)a.stage_begin;
+    for (uint32_t i = lane; i < n; i += 64u) tgt[i] = (int32_t)stages[a.stage_begin].order;
     __builtin_amdgcn_wave_barrier();
-    for (uint32_t s = a.stage_begin; s < a.stage_end && n != 0u; ++s) {
+    for (uint32_t oi = a.stage_begin; oi < a.stage_end && n != 0u; ++oi) {
+        const uint32_t s = stages[oi].order;
         const uint32_t first_node = stages[s].first_node;
         const uint32_t n_nodes = stages[s].n_nodes;
         const float threshold = stages[s].threshold;
@@ -391,7 +424,7 @@ __device__ __forceinline__ void run_stages_general(const CascadeArgs& a, rsrc_t 
             const QEntry e = q[act ? i : 0u];
             int32_t t = tgt[act ? i : 0u];
             const bool here = act && t == (int32_t)s;
-            if (here) t = (stage_sum_of<TREES>(img, tab, n_nodes, e.off, e.var) >= threshold) ? on_pass : on_fail;
+            if (here) t = (stage_sum_of<TREES>(GlobalImg{img}, tab, n_nodes, e.off, e.var) >= threshold) ? on_pass : on_fail;
             const bool keep = act && t >= 0;
             const unsigned long long acc_mask = __ballot(act && t == -1);  // accepted: falls off the tree's end
             if (acc_mask != 0ull) {
@@ -470,7 +503,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
                                                  scales[slot].table_first, lane);
             else
                 run_stages_linear<TREES, LAST, COUNT>(a, img, q, count, slot, scales[slot].table_first,
-                                                      scales[slot].q_base, lane);
+                                                      scales[slot].q_base, lane, a.stage_begin);
             __builtin_amdgcn_wave_barrier();
         }
     } else {
@@ -488,12 +521,155 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
                 const uint32_t n = min(cnt - c0, (uint32_t)UNIT_WINDOWS);
                 for (uint32_t i = lane; i < n; i += 64u) q[i] = a.q_in[(size_t)q_base + c0 + i];
                 __builtin_amdgcn_wave_barrier();
-                run_stages_linear<TREES, LAST, COUNT>(a, img, q, n, slot, table_first, q_base, lane);
+                run_stages_linear<TREES, LAST, COUNT>(a, img, q, n, slot, table_first, q_base, lane, a.stage_begin);
                 __builtin_amdgcn_wave_barrier();
             }
             start += n_chunks;
         }
     }
+}
+
+
+// ------------------------------------------------------------------ LDS-tile pass
+// First pass for the dense small scales.  A workgroup of TILE_WAVES waves owns a tile of
+// 64 x (TILE_WAVES * rw) windows: it stages the tile's footprint of the sum image in LDS
+// with coalesced row loads, then every wave runs the usual compacting stage sweep over
+// its rw rows of windows — but gathers the rectangle corners from LDS instead of
+// through the texture-address unit.  Survivors leave through the same global queues
+// as the global-gather pass, as {global byte offset, variance}.
+template <bool TREES, bool COUNT>
+__global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
+    QEntry* lds_q = reinterpret_cast<QEntry*>(lds_dyn);                   // TILE_WAVES * TILE_WAVE_CAP entries
+    uint32_t* lds_img = lds_dyn + TILE_WAVES * TILE_WAVE_CAP * 2;         // the image tile
+    const uint32_t lane = lane_id();
+    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    QEntry* q = lds_q + wib * TILE_WAVE_CAP;
+    kptr<ScaleDev> scales = as_k(a.scales);
+    kptr<UnitDev> units = as_k(a.tile_units);
+    const uint32_t total_units = a.n_tile_units * a.n_frames;
+    const uint32_t frame_bytes4 = a.frame_elems * 4u;
+
+    for (uint32_t u = blockIdx.x; u < total_units; u += gridDim.x) {
+        const uint32_t frame = u / a.n_tile_units;
+        const uint32_t r = u - frame * a.n_tile_units;
+        const uint32_t slot = units[r].scale;
+        const uint32_t ix0 = units[r].first & 0xffffu, iy0 = units[r].first >> 16;
+        const float step = scales[slot].step;
+        const uint32_t nx = scales[slot].nx, ny = scales[slot].ny;
+        const uint32_t tw = scales[slot].tile_tw, th = scales[slot].tile_th;
+        const uint32_t pitch = scales[slot].tile_pitch, rows = scales[slot].tile_rows;
+        const size_t frame_off = (size_t)frame * a.frame_elems;
+        const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
+        const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
+        // tile origin in the image: the first window's origin (same expression as below)
+        const uint32_t x0 = (uint32_t)__float2int_rn((float)ix0 * step);
+        const uint32_t y0 = (uint32_t)__float2int_rn((float)iy0 * step);
+
+        __syncthreads();  // the previous tile's gathers are finished
+        for (uint32_t rr = wib; rr < rows; rr += TILE_WAVES) {
+            const uint32_t g_row = ((y0 + rr) * a.stride + x0) * 4u;   // uniform
+            for (uint32_t c = lane; c < pitch; c += 64u) lds_img[rr * pitch + c] = ld_u32(sum_f, c * 4u, g_row);
+        }
+        __syncthreads();
+
+        // this wave's share of the tile's tw*th windows: a run of consecutive tile-local indices
+        const uint32_t n_tile = tw * th;
+        // at least one full wave of windows per wave (small tiles leave the last waves idle)
+        const uint32_t per_wave = max(64u, (n_tile + TILE_WAVES - 1u) / TILE_WAVES);   // <= TILE_WAVE_CAP (host)
+        const uint32_t t_begin = min(wib * per_wave, n_tile), t_end = min(t_begin + per_wave, n_tile);
+        uint32_t n = 0;
+        const uint32_t te_lt = scales[slot].te_lt * 4u, te_dh = scales[slot].te_dh * 4u, e_dw = scales[slot].e_dw;
+        const uint32_t e_lt = scales[slot].e_lt, e_dh = scales[slot].e_dh;
+        const float area = scales[slot].area;
+        const LdsImg img{reinterpret_cast<const char*>(lds_img)};
+        for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
+            const uint32_t t = t0 + lane;
+            const uint32_t ty = t / tw, tx = t - ty * tw;
+            const uint32_t iy = iy0 + ty, ix = ix0 + tx;
+            const bool valid = t < t_end && iy < ny && ix < nx;
+            QEntry en{0u, 0.0f};
+            if (valid) {
+                const uint32_t x = (uint32_t)__float2int_rn((float)ix * step);
+                const uint32_t y = (uint32_t)__float2int_rn((float)iy * step);
+                const uint32_t lo4 = ((y - y0) * pitch + (x - x0)) * 4u;   // byte offset inside the tile
+                // computeVariance (clod.cpp:418-446): pixel sum from the LDS tile, squared sum from HBM
+                const uint32_t s4 = img.ld(lo4, te_lt) - img.ld(lo4, te_lt + e_dw * 4u) - img.ld(lo4, te_lt + te_dh) +
+                                    img.ld(lo4, te_lt + te_dh + e_dw * 4u);
+                const uint32_t e = y * a.stride + x;
+                const uint32_t c0 = e_lt, c1 = e_lt + e_dw, c2 = e_lt + e_dh, c3 = e_lt + e_dh + e_dw;
+                const uint64_t q4 = ld_u64(sq_f, e * 8u, c0 * 8u) - ld_u64(sq_f, e * 8u, c1 * 8u) -
+                                    ld_u64(sq_f, e * 8u, c2 * 8u) + ld_u64(sq_f, e * 8u, c3 * 8u);
+                const float mean = (a.signed_mean ? (float)(int32_t)s4 : (float)s4) / area;
+                float variance = (float)q4;
+                variance = (variance / area) - (mean * mean);
+                en.var = variance >= 0.0f ? sqrtf(variance) : 1.0f;
+                en.off = lo4;
+            }
+            const unsigned long long mask = __ballot(valid);
+            if (valid) q[n + mbcnt(mask)] = en;
+            n += (uint32_t)__popcll(mask);
+        }
+        __builtin_amdgcn_wave_barrier();
+        kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + scales[slot].tile_table_first;
+        // Sweep the cascade one pass segment at a time.  Before entering segment p >= 1 the
+        // wave leaves — handing its survivors to queue p — if too few lanes would stay busy
+        // (LDS gathers cost the same for 1 lane as for 64; the queue passes re-pack windows
+        // from the whole batch into full waves) or the segment lies beyond tile_end.
+        uint32_t dest = a.n_pass;   // n_pass = ran the whole cascade: survivors are detections
+        for (uint32_t p = 0; p < a.n_pass && n != 0u; ++p) {
+            if (p != 0u && (n < a.tile_min_lanes || a.pass_begin[p] >= a.tile_end)) {
+                dest = p;
+                break;
+            }
+            n = sweep_stages<TREES, COUNT>(a, img, table, q, n, lane, a.pass_begin[p], a.pass_begin[p + 1]);
+        }
+        if (n != 0u) {
+            // survivors: tile-local offset -> global byte offset in the batch sum image
+            const bool is_det = dest == a.n_pass;
+            uint32_t g = 0;
+            if (lane == 0) g = is_det ? atomicAdd(a.det_count, n) : atomicAdd(a.q_pass_count[dest] + slot, n);
+            g = __builtin_amdgcn_readfirstlane(g);
+            const uint32_t q_base = scales[slot].q_base;
+            const uint32_t frame_bytes = frame * frame_bytes4;
+            QEntry* qd = is_det ? nullptr : a.q_pass[dest];
+            for (uint32_t i = lane; i < n; i += 64u) {
+                const QEntry e = q[i];
+                const uint32_t lo = e.off >> 2;
+                const uint32_t ly = lo / pitch, lx = lo - ly * pitch;
+                const uint32_t off = frame_bytes + ((y0 + ly) * a.stride + (x0 + lx)) * 4u;
+                if (is_det) {
+                    if (g + i < a.det_cap) a.det[g + i] = DetEntry{off, slot};
+                } else {
+                    qd[(size_t)q_base + g + i] = QEntry{off, e.var};
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, int n_blocks, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    static bool attr_set = false;
+    if (!attr_set) {  // allow more than the default 64 KiB of dynamic LDS
+        const int max_lds = 160 * 1024;
+        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        attr_set = true;
+    }
+    dim3 g(n_blocks), b(TILE_WAVES * 64);
+    const size_t lds = a.tile_lds_bytes;
+    if (trees) {
+        if (count) hipLaunchKernelGGL((cascade_tile_pass<true, true>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((cascade_tile_pass<true, false>), g, b, lds, stream, a);
+    } else {
+        if (count) hipLaunchKernelGGL((cascade_tile_pass<false, true>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((cascade_tile_pass<false, false>), g, b, lds, stream, a);
+    }
+    return (int)hipGetLastError();
 }
 
 template <bool FROM_GRID, bool TREES>

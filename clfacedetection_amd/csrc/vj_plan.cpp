@@ -60,7 +60,12 @@ std::vector<vj_scale_info> plan_scales(const vj_cascade& c, int W, int H, const 
 // precomputeKernelCascade (clod.cpp:529-578) for every node of the cascade, in flat
 // node order, into the 64-byte device record.
 int build_node_table(const vj_cascade& c, int width, const vj_scale_info& s, NodeRec* recs) {
-    const uint32_t stride = (uint32_t)width + 1u;
+    return build_node_table_stride(c, (uint32_t)width + 1u, s, recs);
+}
+
+// Same records with the row stride of some other image layout (the LDS tiles of the
+// tile kernel have their own pitch); weights and thresholds do not depend on it.
+int build_node_table_stride(const vj_cascade& c, uint32_t stride, const vj_scale_info& s, NodeRec* recs) {
     const float cs = s.scale;
     const float area = (float)s.area;
     for (size_t t = 0; t < c.trees.size(); ++t) {

@@ -150,7 +150,10 @@ int  vj_env_reserve(vj_env* e, int max_w, int max_h, int max_batch);
 int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
 /* Tunables (results never depend on them): "pass_split" = comma-separated stage
  * indices at which the cascade is cut into separate launches ("" = default),
- * "blocks_per_cu" = persistent workgroups per CU.                               */
+ * "blocks_per_cu" = persistent workgroups per CU of the global-gather passes,
+ * "tile_classes_kb" = "a,b,c" LDS budgets of the image-tile launches ("0,0,0"
+ * turns the LDS-tile path off), "tile_end" = stage at which tile launches stop,
+ * "tile_min_windows" = windows per tile that make a class acceptable.           */
 int  vj_env_configure(vj_env* e, const char* key, const char* value);
 
 /* --------------------------------------------------------------- integral */

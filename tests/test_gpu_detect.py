@@ -105,9 +105,27 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
             env.configure("blocks_per_cu", b)
             r = env.detect(c, frames, p)
             assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, b
+        env.configure("blocks_per_cu", 8)
+        # LDS-tile path off / small / large tiles / shallow / deep: the tile and the
+        # global-gather paths agree bit for bit
+        for classes, tile_end, minw in (("0,0,0", 10, 1024), ("24,40,60", 3, 1024), ("36,64,140", 10, 1024),
+                                        ("36,64,140", 22, 64), ("140,140,140", 14, 2048), ("20,0,0", 7, 128)):
+            env.configure("tile_classes_kb", classes)
+            env.configure("tile_end", tile_end)
+            env.configure("tile_min_windows", minw)
+            env.configure("tile_min_lanes", {3: 0, 10: 12, 22: 64, 14: 1, 7: 200}[tile_end])
+            for split in ("", "22", "7", "2,4,6,9,12,15,18"):
+                env.configure("pass_split", split)
+                r = env.detect(c, frames, p)
+                assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, \
+                    (classes, tile_end, minw, split)
     finally:
         env.configure("pass_split", "")
         env.configure("blocks_per_cu", 8)
+        env.configure("tile_classes_kb", "36,64,140")
+        env.configure("tile_end", 8)
+        env.configure("tile_min_windows", 1024)
+        env.configure("tile_min_lanes", 0)
 
 
 def test_scale_mask_partitions_the_result(env, cascades):

@@ -1,0 +1,73 @@
+"""Ad-hoc performance exploration on the GPU box (not part of the product)."""
+import sys, os, time, json
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from clfacedetection_amd import Cascade, Environment, DeviceFrames, default_params, synth, VJ_FLAG_COUNTERS
+
+env = Environment(0)
+c = Cascade.load("frontalface_alt")
+B = int(os.environ.get("B", "16"))
+frames = synth.batch(B, 1080, 1920, seed0=1)
+t = torch.from_numpy(frames).cuda(); torch.cuda.synchronize()
+df = DeviceFrames.from_torch(t)
+scales = c.plan_scales(1920, 1080)
+
+def run(p, reps=3):
+    env.detect(c, df, p)
+    best = None
+    for _ in range(reps):
+        r = env.detect(c, df, p)
+        if best is None or r.cascade_ms < best.cascade_ms: best = r
+    return best
+
+what = sys.argv[1:] or ["occ", "scales", "split"]
+if "tile" in what:
+    for classes in ("36,64,140",):
+        env.configure("tile_classes_kb", classes)
+        for sp in ("5,10,16", "5,8,11,14,18", "4,6,8,10,13,17", "3,5,7,9,12,16", "5,7,9,12"):
+            for te in (9, 14, 22):
+                for ml in (4, 12, 32):
+                    env.configure("tile_end", te); env.configure("pass_split", sp); env.configure("tile_min_lanes", ml)
+                    r = run(default_params())
+                    print(f"split={sp!r} tile_end={te} min_lanes={ml}: cascade {r.cascade_ms:.2f} ms passes {[round(x[2],2) for x in r.passes]}", flush=True)
+    env.configure("tile_classes_kb", "36,64,140"); env.configure("pass_split", ""); env.configure("tile_end", 8); env.configure("tile_min_lanes", 0)
+if "ab" in what:
+    env.configure("tile_min_lanes", 4096)   # tile waves always leave at the first boundary
+    for k in (0, 4, 8, 10, 12, 14, 16, 20):
+        for sp in ("3", "5", "8"):
+            env.configure("pass_split", sp)
+            out = []
+            for classes in ("0,0,0", "36,64,140"):
+                env.configure("tile_classes_kb", classes)
+                rc = run(default_params(flags=VJ_FLAG_COUNTERS, scales=[k]), 1)
+                r = run(default_params(scales=[k]))
+                ev = sum(rc.stage_entered[i] * int(c.stages["n_trees"][i]) for i in range(int(sp)))
+                out.append(f"{'tile' if classes != '0,0,0' else 'glob'} {r.passes[0][2]:.3f} ms {ev / r.passes[0][2] / 1e6:.1f} Gev/s")
+            print(f"scale {k} s={scales[k].scale:.2f} stages[0,{sp}) windows={rc.windows}: " + " | ".join(out), flush=True)
+    env.configure("tile_classes_kb", "36,64,140"); env.configure("pass_split", ""); env.configure("tile_min_lanes", 0)
+if "minw" in what:
+    for minw in (256, 512, 1024, 2048):
+        env.configure("tile_min_windows", minw)
+        r = run(default_params())
+        print(f"minw={minw}: cascade {r.cascade_ms:.2f} ms passes {[round(x[2],2) for x in r.passes]}", flush=True)
+    env.configure("tile_min_windows", 1024)
+if "occ" in what:
+    for b in (1, 2, 4, 8, 10):
+        env.configure("blocks_per_cu", b)
+        r = run(default_params())
+        print(f"blocks_per_cu={b}: cascade {r.cascade_ms:.2f} ms passes {[round(x[2],2) for x in r.passes]} integral {r.integral_ms:.2f}", flush=True)
+    env.configure("blocks_per_cu", 8)
+if "scales" in what:
+    for k in (0, 4, 8, 12, 16, 20, 24, 30):
+        pc = default_params(flags=VJ_FLAG_COUNTERS, scales=[k])
+        rc = run(pc, 1)
+        r = run(default_params(scales=[k]))
+        s = scales[k]
+        print(f"scale {k} s={s.scale:.2f} step={s.step:.2f} windows={rc.windows} evals/win={rc.stump_evals/max(rc.windows,1):.1f} cascade {r.cascade_ms:.3f} ms -> {rc.windows/r.cascade_ms/1e6:.2f} Gwin/s, {rc.stump_evals/r.cascade_ms/1e6:.1f} Gevals/s passes {[round(x[2],3) for x in r.passes]}", flush=True)
+if "split" in what:
+    for sp in ("22", "3", "5", "4,9,15", "5,10,16", "2,5,10,16", "3,6,9,12,16", "1,2,3,5,8,12,17"):
+        env.configure("pass_split", sp)
+        r = run(default_params())
+        print(f"split {sp}: cascade {r.cascade_ms:.2f} ms passes {[round(x[2],2) for x in r.passes]}", flush=True)
+    env.configure("pass_split", "")
