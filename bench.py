@@ -110,6 +110,8 @@ def main() -> int:
     t0 = time.perf_counter()
     integral_ms = cascade_ms = 0.0
     pass_ms = None
+    launch_ms = None
+    launches = None
     n_det_total = 0
     for _ in range(args.steps):
         r, rects = step(p)
@@ -117,6 +119,9 @@ def main() -> int:
         cascade_ms += r.cascade_ms
         pm = [x[2] for x in r.passes]
         pass_ms = pm if pass_ms is None else [a + b for a, b in zip(pass_ms, pm)]
+        lm = [l["ms"] for l in r.launches]
+        launch_ms = lm if launch_ms is None else [a + b for a, b in zip(launch_ms, lm)]
+        launches = r.launches
         n_det_total = len(rects)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -132,33 +137,53 @@ def main() -> int:
     out = None
     if rank == 0:
         K = max(args.steps, 1)
-        # ---- roofline of the dominant kernel: the first cascade pass (stages [0, k1))
-        # algorithmic bytes: 48 B per window for the variance gathers +
-        # 16 B per evaluated rectangle; per-stage populations come from the counted run.
-        nodes = casc.nodes
-        trees = casc.trees
-        stages = casc.stages
+        # ---- roofline of the dominant kernel.  Launches are grouped by kernel (the names
+        # rocprofv3 --kernel-trace --stats reports); the group with the most time is the
+        # dominant kernel.  Algorithmic bytes: 48 B per window for the
+        # variance gathers + 16 B per evaluated rectangle, from counted runs restricted to
+        # the scales each launch covers; time = HIP events recorded inside the library on
+        # the stream the kernels run on, averaged over the timed steps.
+        nodes, trees, stages = casc.nodes, casc.trees, casc.stages
         rects_per_stage = []
-        for s in stages:
-            tr = trees[s["first_tree"]:s["first_tree"] + s["n_trees"]]
+        for st in stages:
+            tr = trees[st["first_tree"]:st["first_tree"] + st["n_trees"]]
             rects_per_stage.append(int(sum(int(nodes["n_rects"][t["first_node"]:t["first_node"] + t["n_nodes"]].sum())
                                            for t in tr)))
-        b0, e0, _ = counted.passes[0]
-        alg_bytes_pass0 = 48 * counted.windows + 16 * sum(counted.stage_entered[s] * rects_per_stage[s]
-                                                         for s in range(b0, e0))
-        pass0_ms = pass_ms[0] / K
-        achieved = alg_bytes_pass0 / (pass0_ms * 1e-3) / 1e9
+        kname = {"tile": "vj::cascade_tile_pass<false, false>", "grid": "vj::cascade_pass<true, false, *, false, false>",
+                 "queue": "vj::cascade_pass<false, false, *, false, false>"}
+        groups = {}
+        for l, ms in zip(launches, launch_ms):
+            g = groups.setdefault(l["kind"], {"ms": 0.0, "n": 0, "launches": []})
+            g["ms"] += ms / K
+            g["n"] += 1
+            g["launches"].append(l)
+        dom_kind = max(groups, key=lambda k: groups[k]["ms"])
+        dom = groups[dom_kind]
+        alg = 0
+        all_scales = sorted({k for l in launches for k in l["scales"]})
+        for l in dom["launches"]:
+            sub = counted if l["scales"] == all_scales else \
+                env.detect(casc, dframes, default_params(flags=VJ_FLAG_COUNTERS, scales=l["scales"]))
+            if l["kind"] != "queue":
+                alg += 48 * sub.windows
+            alg += 16 * sum(sub.stage_entered[st] * rects_per_stage[st] for st in range(l["stage_begin"], l["stage_end"]))
+        achieved = alg / (dom["ms"] * 1e-3) / 1e9
         traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_pass0.json")   # written by tools/pmc_summary.py from rocprofv3 --pmc
+        pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")   # from rocprofv3 --pmc passes (tools/pmc_traffic.py)
         if os.path.exists(pmc):
             try:
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+                j = json.load(open(pmc))
+                if j.get("kernel_kind") == dom_kind:
+                    traffic = j.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
-        roofline = {"bound": "hbm", "kernel": f"cascade_pass<from_grid> stages [{b0},{e0})",
+        roofline = {"bound": "hbm", "kernel": kname[dom_kind], "launches_per_step": dom["n"],
                     "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(alg_bytes_pass0), "avg_launch_ms": round(pass0_ms, 4)}
+                    "algorithmic_bytes_per_launch": int(alg // dom["n"]),
+                    "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
+                    "note": "gathers are served from LDS tiles / L2, not HBM: see DESIGN.md for the LDS and "
+                            "texture-address ceilings that actually bound these kernels"}
 
         # ---- CPU baseline: the oracle, 1 thread, on the first --cpu-frames frames (also a parity check)
         cpu = None
@@ -194,7 +219,10 @@ def main() -> int:
             "frames_per_s": round(B * world * args.steps / elapsed, 1),
             "detections_last_step": int(n_det_total),
             "kernel_ms_per_step": {"integral": round(integral_ms / K, 4), "cascade": round(cascade_ms / K, 4),
-                                   "cascade_passes": [round(x / K, 4) for x in pass_ms]},
+                                   "cascade_passes": [round(x / K, 4) for x in pass_ms],
+                                   "launches": [{"kind": l["kind"], "lds_class": l["lds_class"],
+                                                 "stages": [l["stage_begin"], l["stage_end"]], "n_scales": len(l["scales"]),
+                                                 "ms": round(ms / K, 4)} for l, ms in zip(launches, launch_ms)]},
             "stump_evals_per_window": round(counted.stump_evals / max(counted.windows, 1), 3),
             "cascade_algorithmic_GBps": round(counted.gather_bytes / (cascade_ms / K * 1e-3) / 1e9, 2),
             "roofline": roofline, "cpu_baseline": cpu, "parity_sample_ok": parity,

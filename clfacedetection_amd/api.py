@@ -76,12 +76,20 @@ class _Counters(C.Structure):
 
 
 VJ_MAX_PASSES = 8
+VJ_MAX_LAUNCHES = 16
+LAUNCH_KINDS = {0: "grid", 1: "queue", 2: "tile"}
+
+
+class _Launch(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("lds_class", C.c_int32), ("stage_begin", C.c_int32), ("stage_end", C.c_int32),
+                ("ms", C.c_float), ("lds_bytes", C.c_uint32), ("scale_mask", C.c_uint64 * 2)]
 
 
 class _Timing(C.Structure):
     _fields_ = [("integral_ms", C.c_float), ("cascade_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_cascade_launches", C.c_int32), ("pass_ms", C.c_float * VJ_MAX_PASSES),
-                ("pass_stage_begin", C.c_int32 * VJ_MAX_PASSES), ("pass_stage_end", C.c_int32 * VJ_MAX_PASSES)]
+                ("pass_stage_begin", C.c_int32 * VJ_MAX_PASSES), ("pass_stage_end", C.c_int32 * VJ_MAX_PASSES),
+                ("n_launches", C.c_int32), ("launch", _Launch * VJ_MAX_LAUNCHES)]
 
 
 class _Result(C.Structure):
@@ -260,7 +268,8 @@ class DetectResult:
     cascade_ms: float
     total_ms: float
     n_cascade_launches: int
-    passes: list = None          # [(stage_begin, stage_end, ms)] per cascade launch
+    passes: list = None          # [(stage_begin, stage_end, ms)] per cascade pass
+    launches: list = None        # per kernel launch: dict(kind, lds_class, stage_begin, stage_end, ms, lds_bytes, scales)
 
     @property
     def match_count(self) -> int:
@@ -337,7 +346,12 @@ class Environment:
                                 float(t.integral_ms), float(t.cascade_ms), float(t.total_ms),
                                 int(t.n_cascade_launches),
                                 [(int(t.pass_stage_begin[i]), int(t.pass_stage_end[i]), float(t.pass_ms[i]))
-                                 for i in range(min(int(t.n_cascade_launches), VJ_MAX_PASSES))])
+                                 for i in range(min(int(t.n_cascade_launches), VJ_MAX_PASSES))],
+                                [dict(kind=LAUNCH_KINDS.get(int(l.kind), "?"), lds_class=int(l.lds_class),
+                                      stage_begin=int(l.stage_begin), stage_end=int(l.stage_end), ms=float(l.ms),
+                                      lds_bytes=int(l.lds_bytes),
+                                      scales=[k for k in range(128) if (l.scale_mask[k >> 6] >> (k & 63)) & 1])
+                                 for l in list(t.launch)[:int(t.n_launches)]])
         finally:
             lib.vj_result_free(C.byref(res))
 

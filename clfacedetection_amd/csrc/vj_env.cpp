@@ -86,6 +86,7 @@ struct vj_env {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pass_ev[VJ_MAX_PASSES + 1] = {};
+    hipEvent_t launch_ev[VJ_MAX_LAUNCHES + 1] = {};
     char name[256] = "";
     int n_cu = 0;
     // image buffers
@@ -560,6 +561,24 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.tile_end = (uint32_t)e->tile_end;
         ca.tile_min_lanes = (uint32_t)e->tile_min_lanes;
         int launches = 0;
+        std::vector<vj_launch> linfo;
+        auto begin_launch = [&](int kind, int cls, uint32_t sb, uint32_t se, uint32_t lds) -> int {
+            if (linfo.size() < VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(e->launch_ev[linfo.size()], e->stream));
+            vj_launch li;
+            memset(&li, 0, sizeof(li));
+            li.kind = kind;
+            li.lds_class = cls;
+            li.stage_begin = (int32_t)sb;
+            li.stage_end = (int32_t)se;
+            li.lds_bytes = lds;
+            for (const ScaleDev& sd : pl->scales) {
+                const bool in = kind == VJ_LAUNCH_QUEUE || (kind == VJ_LAUNCH_TILE && sd.tile_rw && (int)sd.tile_class == cls) ||
+                                (kind == VJ_LAUNCH_GRID && !sd.tile_rw);
+                if (in && sd.scale_idx < 128) li.scale_mask[sd.scale_idx >> 6] |= 1ull << (sd.scale_idx & 63);
+            }
+            linfo.push_back(li);
+            return VJ_OK;
+        };
         if (ca.n_units + ca.n_tile_units > 0) {
             for (size_t ps = 0; ps < n_pass; ++ps) {
                 ca.stage_begin = pl->pass_bounds[ps];
@@ -585,9 +604,15 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                         const int per_cu = std::max(1, std::min(4, (int)(160u * 1024u / ta.tile_lds_bytes)));
                         const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf,
                                                                (uint64_t)e->n_cu * (uint64_t)per_cu);
+                        const uint32_t deepest = std::min<uint32_t>((uint32_t)pl->stages.size(),
+                                                                    std::max<uint32_t>(ca.tile_end, pl->pass_bounds[1]));
+                        if ((rc = begin_launch(VJ_LAUNCH_TILE, (int)cls, 0, deepest, ta.tile_lds_bytes))) return rc;
                         hrc = launch_cascade_tile_pass(ta, pl->trees, count, std::max(1, tb), e->stream);
                     }
                 }
+                if (!hrc && (ps > 0 || ca.n_units > 0) &&
+                    (rc = begin_launch(ps == 0 ? VJ_LAUNCH_GRID : VJ_LAUNCH_QUEUE, 0, ca.stage_begin, ca.stage_end, 0)))
+                    return rc;
                 if (!hrc && (ps > 0 || ca.n_units > 0))
                     hrc = launch_cascade_pass(ca, ps == 0, pl->trees, last, count, pl->general, n_blocks, e->stream);
                 if (hrc) {
@@ -598,6 +623,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             }
         }
         if (n_pass <= VJ_MAX_PASSES && launches) HIP_TRY(hipEventRecord(e->pass_ev[n_pass], e->stream));
+        if (linfo.size() <= VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(e->launch_ev[linfo.size()], e->stream));
         HIP_TRY(hipEventRecord(e->ev[3], e->stream));
         // read back the counters block
         HIP_TRY(hipMemcpyAsync(e->h_pinned, e->d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
@@ -626,6 +652,16 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 tm->pass_stage_end[ps] = (int32_t)pl->pass_bounds[ps + 1];
             }
         tm->n_cascade_launches = std::max(tm->n_cascade_launches, launches);
+        if (linfo.size() <= VJ_MAX_LAUNCHES) {
+            for (size_t i = 0; i < linfo.size(); ++i) {
+                float ms = 0;
+                HIP_TRY(hipEventElapsedTime(&ms, e->launch_ev[i], e->launch_ev[i + 1]));
+                const float prev = tm->launch[i].ms;
+                tm->launch[i] = linfo[i];
+                tm->launch[i].ms = prev + ms;
+            }
+            tm->n_launches = (int32_t)linfo.size();
+        }
         if (count) {
             const unsigned long long* se =
                 (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * MAX_SCALES + 2);
@@ -680,6 +716,7 @@ int vj_env_create(int device_index, vj_env** out) {
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     for (auto& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
     for (auto& ev : e->pass_ev) HIP_TRY(hipEventCreate(&ev));
+    for (auto& ev : e->launch_ev) HIP_TRY(hipEventCreate(&ev));
     e->h_pinned_bytes = 8192;
     HIP_TRY(hipHostMalloc(&e->h_pinned, e->h_pinned_bytes, hipHostMallocDefault));
     if (const char* s = getenv("VJ_BLOCKS_PER_CU")) e->blocks_per_cu = std::max(1, atoi(s));
@@ -709,6 +746,8 @@ void vj_env_destroy(vj_env* e) {
     for (auto& ev : e->ev)
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->pass_ev)
+        if (ev) (void)hipEventDestroy(ev);
+    for (auto& ev : e->launch_ev)
         if (ev) (void)hipEventDestroy(ev);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;

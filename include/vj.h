@@ -187,14 +187,28 @@ typedef struct vj_counters {
 } vj_counters;
 
 #define VJ_MAX_PASSES 8
+#define VJ_MAX_LAUNCHES 16
+enum { VJ_LAUNCH_GRID = 0,   /* first pass, windows enumerated from the grid, L2 gathers */
+       VJ_LAUNCH_QUEUE = 1,  /* later pass over the survivor queue, L2 gathers           */
+       VJ_LAUNCH_TILE = 2 }; /* first pass(es) on image tiles staged in LDS              */
+typedef struct vj_launch {
+    int32_t  kind;             /* VJ_LAUNCH_*                                   */
+    int32_t  lds_class;        /* tile launches: LDS size class                 */
+    int32_t  stage_begin, stage_end;  /* stages it may run (tile launches: up to stage_end) */
+    float    ms;               /* HIP-event time, summed over sub-batches       */
+    uint32_t lds_bytes;
+    uint64_t scale_mask[2];    /* scale indices it covers (queue passes: all)   */
+} vj_launch;
 typedef struct vj_timing {     /* HIP-event times of the last vj_detect, ms     */
     float integral_ms;         /* the three integral launches                   */
     float cascade_ms;          /* all cascade passes                            */
     float total_ms;            /* first kernel start → last kernel end          */
     int32_t n_cascade_launches;
-    float pass_ms[VJ_MAX_PASSES];            /* each cascade launch             */
+    float pass_ms[VJ_MAX_PASSES];            /* each cascade pass (its launches) */
     int32_t pass_stage_begin[VJ_MAX_PASSES]; /* stages [begin, end) it ran      */
     int32_t pass_stage_end[VJ_MAX_PASSES];
+    int32_t n_launches;                      /* kernel launches of the cascade  */
+    vj_launch launch[VJ_MAX_LAUNCHES];       /* each with its own HIP events    */
 } vj_timing;
 
 typedef struct vj_result {
