@@ -223,6 +223,10 @@ def main() -> int:
                                    "launches": [{"kind": l["kind"], "lds_class": l["lds_class"],
                                                  "stages": [l["stage_begin"], l["stage_end"]], "n_scales": len(l["scales"]),
                                                  "ms": round(ms / K, 4)} for l, ms in zip(launches, launch_ms)]},
+            # the one genuinely HBM-bound kernel group: 1 B read + 12 B written per pixel
+            "integral_roofline": {"bound": "hbm", "achieved": round(13 * W * H * B / (integral_ms / K * 1e-3) / 1e9, 1),
+                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                  "frac": round(13 * W * H * B / (integral_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "stump_evals_per_window": round(counted.stump_evals / max(counted.windows, 1), 3),
             "cascade_algorithmic_GBps": round(counted.gather_bytes / (cascade_ms / K * 1e-3) / 1e9, 2),
             "roofline": roofline, "cpu_baseline": cpu, "parity_sample_ok": parity,

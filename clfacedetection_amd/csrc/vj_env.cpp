@@ -102,6 +102,7 @@ struct vj_env {
     int blocks_per_cu = 8;
     int tile_class_kb[TILE_CLASSES] = {36, 64, 140};  // image-tile LDS budget per class; all 0 disables the tile path
     int tile_min_windows = 1024;  // a class is acceptable for a scale when a tile holds at least this many windows
+    int tile_accept_windows = 512;  // scales whose best tile holds fewer windows stay on the global-gather path
     int tile_end = 8;             // tile launches never enter a pass that begins at or beyond this stage
     int tile_min_lanes = 0;       // a tile wave leaves at a pass boundary when fewer windows than this survive
     std::vector<int> split_override;
@@ -277,7 +278,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                         best_cls = cls; best_n = nwt; b_tw = tw; b_th = th; b_pitch = pitch; b_rows = rows;
                     }
             }
-            if (best_n >= 128) {
+            if (best_n >= (uint32_t)e->tile_accept_windows) {
                 sd.tile_rw = 1;
                 sd.tile_tw = b_tw;
                 sd.tile_th = b_th;
@@ -807,15 +808,17 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         drop_plans(e);
         return VJ_OK;
     }
-    if (strcmp(key, "tile_min_windows") == 0 || strcmp(key, "tile_end") == 0 || strcmp(key, "tile_min_lanes") == 0) {
+    if (strcmp(key, "tile_min_windows") == 0 || strcmp(key, "tile_end") == 0 || strcmp(key, "tile_min_lanes") == 0 ||
+        strcmp(key, "tile_accept_windows") == 0) {
         const int v = atoi(value);
         if (v < 0 || v > 4096) {
             set_error("%s out of range", key);
             return VJ_ERR_ARG;
         }
-        (strcmp(key, "tile_min_windows") == 0 ? e->tile_min_windows
-         : strcmp(key, "tile_end") == 0       ? e->tile_end
-                                              : e->tile_min_lanes) = v;
+        (strcmp(key, "tile_min_windows") == 0      ? e->tile_min_windows
+         : strcmp(key, "tile_end") == 0           ? e->tile_end
+         : strcmp(key, "tile_accept_windows") == 0 ? e->tile_accept_windows
+                                                  : e->tile_min_lanes) = v;
         HIP_TRY(hipStreamSynchronize(e->stream));
         drop_plans(e);
         return VJ_OK;

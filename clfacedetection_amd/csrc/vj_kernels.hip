@@ -131,6 +131,9 @@ __device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, uint32_t lane) {
     return v;
 }
 
+typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
+typedef uint64_t u64x2_unaligned __attribute__((ext_vector_type(2), aligned(8)));
+
 __global__ __launch_bounds__(256) void band_rows(IntegralArgs a) {
     const uint32_t lane = lane_id();
     const uint32_t band = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -192,12 +195,21 @@ __global__ __launch_bounds__(256) void band_rows(IntegralArgs a) {
                     sum[ro] = 0u;
                     sqs[ro] = 0ull;
                 }
+                if (x + 4u <= a.width) {
+                    // 16 (sum) and 32 (squared sum) contiguous bytes per lane: the wave writes
+                    // contiguous 1 KiB / 2 KiB runs; rows are only 4-byte aligned (odd stride)
+                    *reinterpret_cast<u32x4_unaligned*>(sum + ro + x + 1u) =
+                        u32x4_unaligned{base_s + ls[0], base_s + ls[1], base_s + ls[2], base_s + ls[3]};
+                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 1u) = u64x2_unaligned{base_q + lq[0], base_q + lq[1]};
+                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 3u) = u64x2_unaligned{base_q + lq[2], base_q + lq[3]};
+                } else {
 #pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    if (x + c < a.width) {
-                        sum[ro + x + c + 1u] = base_s + ls[c];
-                        sqs[ro + x + c + 1u] = base_q + lq[c];
-                    }
+                    for (int c = 0; c < 4; ++c)
+                        if (x + c < a.width) {
+                            sum[ro + x + c + 1u] = base_s + ls[c];
+                            sqs[ro + x + c + 1u] = base_q + lq[c];
+                        }
+                }
                 rs[r] += __shfl(is, 63, 64);
                 rq[r] += __shfl(iq, 63, 64);
             }
@@ -281,6 +293,7 @@ __device__ __forceinline__ float stage_sum_stumps(const Img& img, kptr<NodeRecDe
                                                   float var) {
     float stage_sum = 0.0f;
     NodeRecDev r = tab[0];
+#pragma unroll 2
     for (uint32_t j = 0; j < n_nodes; ++j) {
         // fetch the next record while this one is evaluated (scalar loads are long)
         const NodeRecDev rn = tab[j + 1 < n_nodes ? j + 1 : j];

@@ -46,6 +46,14 @@ if "ab" in what:
                 out.append(f"{'tile' if classes != '0,0,0' else 'glob'} {r.passes[0][2]:.3f} ms {ev / r.passes[0][2] / 1e6:.1f} Gev/s")
             print(f"scale {k} s={scales[k].scale:.2f} stages[0,{sp}) windows={rc.windows}: " + " | ".join(out), flush=True)
     env.configure("tile_classes_kb", "36,64,140"); env.configure("pass_split", ""); env.configure("tile_min_lanes", 0)
+if "accept" in what:
+    for classes in ("36,64,140", "36,64,100", "36,72,0", "40,80,0", "52,80,0", "52,80,140"):
+        env.configure("tile_classes_kb", classes)
+        for minw, acc in ((1024, 128), (1024, 512), (1024, 1024), (512, 512), (2048, 1024), (2048, 512)):
+            env.configure("tile_min_windows", minw); env.configure("tile_accept_windows", acc)
+            r = run(default_params())
+            print(f"classes={classes} minw={minw} accept={acc}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("tile_classes_kb", "36,64,140"); env.configure("tile_min_windows", 1024); env.configure("tile_accept_windows", 512)
 if "minw" in what:
     for minw in (256, 512, 1024, 2048):
         env.configure("tile_min_windows", minw)
