@@ -133,6 +133,7 @@ _SIGNATURES = {
     "vj_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.POINTER(Params),
                             C.POINTER(_Result)]),
     "vj_result_free": (None, [C.POINTER(_Result)]),
+    "vj_group_rectangles": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_double]),
     "vj_count_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(C.c_uint64)]),
 }
 
@@ -383,6 +384,15 @@ class DeviceFrames:
         assert t.is_cuda and t.dtype.itemsize == 1 and t.dim() == 3 and t.is_contiguous()
         n, h, w = t.shape
         return cls(t.data_ptr(), n, h, w, w)
+
+
+def group_rectangles(rects: np.ndarray, group_threshold: int, eps: float = 0.2) -> np.ndarray:
+    """filterResult / cv::groupRectangles on a RECT_DTYPE array sorted by frame (host logic)."""
+    buf = np.ascontiguousarray(rects, RECT_DTYPE).copy()
+    n = C.c_uint32(len(buf))
+    _check(load_library().vj_group_rectangles(buf.ctypes.data if len(buf) else None, C.byref(n), int(group_threshold),
+                                              float(eps)), "vj_group_rectangles")
+    return buf[:n.value]
 
 
 # ------------------------------------------------- reference-named entry points

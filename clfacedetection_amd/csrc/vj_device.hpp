@@ -80,6 +80,7 @@ constexpr int TILE_WAVES = 8;        // waves per workgroup of the LDS-tile kern
 constexpr int TILE_W = 64;           // windows per tile row (= lanes of a wave)
 constexpr int TILE_WAVE_CAP = 256;    // windows (= LDS queue entries) per wave of the tile kernel
 constexpr int TILE_CLASSES = 3;       // LDS size classes, one launch each
+constexpr int TILE_LDS_HEADER = (TILE_WAVES * TILE_WAVE_CAP * 2 + 16) * 4;  // queues + per-wave counts, bytes
 
 struct CascadeArgs {
     const uint32_t* sum;        // batch sum images, frame f at f * frame_elems
@@ -111,7 +112,8 @@ struct CascadeArgs {
     QEntry*   q_pass[MAX_PASSES];           // q_pass[p]: windows waiting to enter segment p (p >= 1)
     uint32_t* q_pass_count[MAX_PASSES];
     uint32_t  tile_end;                     // deepest stage a tile launch may enter
-    uint32_t  tile_min_lanes;
+    uint32_t  tile_min_lanes;               // leave at a pass boundary when the whole tile has fewer survivors
+    unsigned long long tile_repack_mask;    // bit s: re-pack the tile's survivors across its waves before stage s
     DetEntry* det;              // detections (last pass)
     uint32_t* det_count;
     uint32_t  det_cap;

@@ -104,7 +104,8 @@ struct vj_env {
     int tile_min_windows = 1024;  // a class is acceptable for a scale when a tile holds at least this many windows
     int tile_accept_windows = 512;  // scales whose best tile holds fewer windows stay on the global-gather path
     int tile_end = 8;             // tile launches never enter a pass that begins at or beyond this stage
-    int tile_min_lanes = 0;       // a tile wave leaves at a pass boundary when fewer windows than this survive
+    int tile_min_lanes = 0;       // a tile leaves at a pass boundary when fewer windows than this survive in it
+    unsigned long long tile_repack_mask = (1ull << 3) | (1ull << 5);  // stages before which a tile re-packs its survivors
     std::vector<int> split_override;
 };
 
@@ -335,7 +336,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                     pl->tile_units.push_back(UnitDev{slot, ix0 | (iy0 << 16), 0, 0});
             pl->class_lds[cls] = std::max(pl->class_lds[cls], sd.tile_pitch * sd.tile_rows * 4u);
         }
-        if (pl->class_lds[cls]) pl->class_lds[cls] += TILE_WAVES * TILE_WAVE_CAP * (uint32_t)sizeof(QEntry);
+        if (pl->class_lds[cls]) pl->class_lds[cls] += TILE_LDS_HEADER;
     }
     pl->class_first[TILE_CLASSES] = (uint32_t)pl->tile_units.size();
 
@@ -561,6 +562,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         }
         ca.tile_end = (uint32_t)e->tile_end;
         ca.tile_min_lanes = (uint32_t)e->tile_min_lanes;
+        ca.tile_repack_mask = e->tile_repack_mask;
         int launches = 0;
         std::vector<vj_launch> linfo;
         auto begin_launch = [&](int kind, int cls, uint32_t sb, uint32_t se, uint32_t lds) -> int {
@@ -823,6 +825,21 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         drop_plans(e);
         return VJ_OK;
     }
+    if (strcmp(key, "tile_repack") == 0) {  // "3,5": stages before which tiles re-pack ("" = never)
+        unsigned long long m = 0;
+        for (const char* q = value; *q;) {
+            char* endp;
+            long x = strtol(q, &endp, 10);
+            if (endp == q || x < 1 || x > 63) {
+                set_error("tile_repack: expected comma-separated stage indices in [1,63]");
+                return VJ_ERR_ARG;
+            }
+            m |= 1ull << x;
+            q = *endp ? endp + 1 : endp;
+        }
+        e->tile_repack_mask = m;
+        return VJ_OK;
+    }
     if (strcmp(key, "blocks_per_cu") == 0) {
         const int v = atoi(value);
         if (v < 1 || v > 16) {
@@ -873,10 +890,6 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
         set_error("scale_factor must be > 1");
         return VJ_ERR_ARG;
     }
-    if (p->min_neighbors != 0) {
-        set_error("min_neighbors != 0 (grouping) is not part of the raw-candidate contract yet");
-        return VJ_ERR_UNSUPPORTED;
-    }
     const int W = frames[0].width, H = frames[0].height;
     if (W <= 0 || H <= 0) return VJ_ERR_ARG;
     for (int i = 0; i < n_frames; ++i) {
@@ -925,6 +938,10 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
             out->rects[i] = vj_rect{(int32_t)dets[i].x, (int32_t)dets[i].y, si.win_w, si.win_h, 0.0f, dets[i].frame,
                                     si.scale_idx};
         }
+    }
+    if (p->min_neighbors != 0 && out->count) {  // clod.cpp:1325-1326: filterResult(matches, n, MAX(min_neighbors, 1), EPS)
+        rc = vj_group_rectangles(out->rects, &out->count, (int)std::max<uint32_t>(p->min_neighbors, 1u), 0.2);
+        if (rc) return rc;
     }
     if (p->flags & VJ_FLAG_COUNTERS) {
         vj_counters& k = out->counters;

@@ -554,7 +554,8 @@ template <bool TREES, bool COUNT>
 __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
     QEntry* lds_q = reinterpret_cast<QEntry*>(lds_dyn);                   // TILE_WAVES * TILE_WAVE_CAP entries
-    uint32_t* lds_img = lds_dyn + TILE_WAVES * TILE_WAVE_CAP * 2;         // the image tile
+    uint32_t* lds_cnt = lds_dyn + TILE_WAVES * TILE_WAVE_CAP * 2;         // survivors per wave (re-packing)
+    uint32_t* lds_img = lds_dyn + TILE_LDS_HEADER / 4;                    // the image tile
     const uint32_t lane = lane_id();
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     QEntry* q = lds_q + wib * TILE_WAVE_CAP;
@@ -586,6 +587,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         }
         __syncthreads();
 
+        q = lds_q + wib * TILE_WAVE_CAP;   // (re-packing below moves the wave's queue base)
         // this wave's share of the tile's tw*th windows: a run of consecutive tile-local indices
         const uint32_t n_tile = tw * th;
         // at least one full wave of windows per wave (small tiles leave the last waves idle)
@@ -625,17 +627,53 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         }
         __builtin_amdgcn_wave_barrier();
         kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + scales[slot].tile_table_first;
-        // Sweep the cascade one pass segment at a time.  Before entering segment p >= 1 the
-        // wave leaves — handing its survivors to queue p — if too few lanes would stay busy
-        // (LDS gathers cost the same for 1 lane as for 64; the queue passes re-pack windows
-        // from the whole batch into full waves) or the segment lies beyond tile_end.
+        // Sweep the cascade stage by stage.  At the stages named by tile_repack_mask and at every
+        // pass boundary the tile's survivors are re-packed across its waves into runs of full
+        // 64-lane chunks (gathers cost the same for 1 lane as for 64, so 8 thin waves would pay 8x).
+        // At a pass boundary the whole workgroup leaves — handing its survivors to that pass's
+        // queue — when the boundary lies at or beyond tile_end or fewer than tile_min_lanes
+        // windows are left in the tile (the queue passes re-pack windows of the whole batch).
         uint32_t dest = a.n_pass;   // n_pass = ran the whole cascade: survivors are detections
-        for (uint32_t p = 0; p < a.n_pass && n != 0u; ++p) {
-            if (p != 0u && (n < a.tile_min_lanes || a.pass_begin[p] >= a.tile_end)) {
-                dest = p;
-                break;
+        uint32_t next_p = 1;        // next pass boundary index
+        const uint32_t n_stages_total = a.pass_begin[a.n_pass];
+        for (uint32_t st = 0; st < n_stages_total; ++st) {
+            const bool at_boundary = next_p < a.n_pass && st == a.pass_begin[next_p];
+            if (st != 0u && (at_boundary || ((a.tile_repack_mask >> st) & 1ull))) {
+                // ---- workgroup-uniform: count, then move every survivor to its packed position
+                if (lane == 0) lds_cnt[wib] = n;
+                __syncthreads();
+                uint32_t before = 0, total = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < TILE_WAVES; ++w) {
+                    const uint32_t c = lds_cnt[w];
+                    before += w < wib ? c : 0u;
+                    total += c;
+                }
+                before = __builtin_amdgcn_readfirstlane(before);
+                total = __builtin_amdgcn_readfirstlane(total);
+                QEntry hold[TILE_WAVE_CAP / 64];
+#pragma unroll
+                for (uint32_t k = 0; k < TILE_WAVE_CAP / 64; ++k)
+                    if (k * 64u + lane < n) hold[k] = q[k * 64u + lane];
+                __syncthreads();   // every wave holds its survivors in registers
+#pragma unroll
+                for (uint32_t k = 0; k < TILE_WAVE_CAP / 64; ++k)
+                    if (k * 64u + lane < n) lds_q[before + k * 64u + lane] = hold[k];
+                __syncthreads();
+                // contiguous shares of whole chunks: wave w owns [w*share, (w+1)*share)
+                const uint32_t share = 64u * (((total + 63u) / 64u + TILE_WAVES - 1u) / TILE_WAVES);
+                const uint32_t first = min(wib * share, total);
+                q = lds_q + first;
+                n = min(share, total - first);
+                if (at_boundary) {
+                    if (total < max(a.tile_min_lanes, 1u) || st >= a.tile_end) {
+                        dest = next_p;
+                        break;
+                    }
+                    ++next_p;
+                }
             }
-            n = sweep_stages<TREES, COUNT>(a, img, table, q, n, lane, a.pass_begin[p], a.pass_begin[p + 1]);
+            if (n != 0u) n = sweep_stages<TREES, COUNT>(a, img, table, q, n, lane, st, st + 1u);
         }
         if (n != 0u) {
             // survivors: tile-local offset -> global byte offset in the batch sum image

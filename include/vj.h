@@ -108,7 +108,7 @@ typedef struct vj_params {
     int32_t  min_w, min_h;     /* min_window_size (0 = none)                    */
     int32_t  max_w, max_h;     /* max_window_size (0 = unlimited, clod.cpp:394) */
     float    scale_factor;     /* reference hard-codes 1.1f (clod.cpp:1184)     */
-    uint32_t min_neighbors;    /* 0 = raw candidates (the parity contract)      */
+    uint32_t min_neighbors;    /* 0 = raw candidates (the parity contract); else grouped */
     uint32_t flags;
     uint64_t scale_mask[2];    /* bit k set = evaluate scale index k (k < 128); both
                                   words 0 = every scale.  Shards one frame's scales
@@ -223,6 +223,12 @@ typedef struct vj_result {
 int  vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames,
                const vj_params* p, vj_result* out);
 void vj_result_free(vj_result* r);
+
+/* filterResult (clod.cpp:182-357) as cv::groupRectangles defines it (tempcv.cpp:130-243): groups
+ * `rects` (sorted by frame; grouped per frame, in place), keeps classes with more than
+ * group_threshold members, weight = members, scale_idx = -1.  vj_detect applies it with
+ * MAX(min_neighbors, 1) and eps 0.2 (clod.cpp:11, 1326) when min_neighbors != 0.            */
+int vj_group_rectangles(vj_rect* rects, uint32_t* count, int group_threshold, double eps);
 
 /* Candidate windows per frame for (cascade, size, params): sum of nx*ny over
  * accepted scales — the denominator of the windows/s metric.                   */

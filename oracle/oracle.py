@@ -250,6 +250,8 @@ class Oracle:
         L.oc_xorshift_noise.restype = None
         L.oc_u64_to_f32.argtypes = [C.c_uint64]
         L.oc_u64_to_f32.restype = C.c_float
+        L.oc_group_rectangles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
+        L.oc_group_rectangles.restype = C.c_int
 
     @staticmethod
     def _cstruct(c: CascadeArrays) -> tuple[_OcCascade, list]:
@@ -328,6 +330,14 @@ class Oracle:
                  "gather_bytes": 48 * int(st.windows) + 16 * int(st.rect_evals),
                  "stage_entered": [int(v) for v in st.stage_entered[:c.n_stages]]}
         return r, stats
+
+    # f1 (next row): grouping
+    def group_rectangles(self, xywh: np.ndarray, group_threshold: int, eps: float = 0.2):
+        """xywh: (n, 4) int array in detection order -> (grouped (m, 4), weights (m,))."""
+        r = np.ascontiguousarray(xywh, np.int32).reshape(-1, 4).copy()
+        w = np.zeros(max(len(r), 1), np.int32)
+        m = self.lib.oc_group_rectangles(r.ctypes.data, len(r), group_threshold, eps, w.ctypes.data)
+        return r[:m], w[:m]
 
     def xorshift_noise(self, seed: int, h: int, w: int) -> np.ndarray:
         img = np.zeros((h, w), np.uint8)

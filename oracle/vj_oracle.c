@@ -14,7 +14,8 @@
  * per-stage survivor counts, stump-evaluation totals, raw detection counts) — see
  * tests/test_oracle_pins.py.  For tree cascades (frontalface_alt2, _alt_tree) the
  * reference's clod path itself is wrong (SURVEY.md §2.2-3,4): parity there is
- * UNPINNED beyond this file and its numpy twin (oracle/np_oracle.py).
+ * UNPINNED beyond this file and its independent numpy twin (oracle/np_oracle.py,
+ * tests/test_np_twin.py).
  *
  * Every function cites the reference lines it follows (paths relative to
  * CLFaceDetection/).  All float arithmetic is IEEE binary32 in the written order;
@@ -403,3 +404,101 @@ void oc_xorshift_noise(uint32_t seed, uint8_t* dst, size_t n) {
 
 /* u64 -> f32 conversion probe, for known-answer tests of the device conversion. */
 float oc_u64_to_f32(uint64_t v) { return (float)v; }
+
+/* ------------------------------------------------------ f1: grouping (next row) */
+/* cv::groupRectangles as the reference keeps it in tempcv.cpp:130-243 (the clod port
+ * clod.cpp:182-357 is buggy).  cv::partition is OpenCV 2.4.2 core
+ * (operations.hpp, not in the reference tree): disjoint-set forest with rank and path
+ * compression over all ordered pairs, classes numbered in order of first appearance —
+ * restated here as published.  UNPINNED: the reference has no grouping outputs to compare. */
+typedef struct oc_grect { int32_t x, y, w, h; } oc_grect;
+
+static int oc_similar(const oc_grect* r1, const oc_grect* r2, double eps) {
+    int mw = r1->w < r2->w ? r1->w : r2->w, mh = r1->h < r2->h ? r1->h : r2->h;
+    double delta = eps * (mw + mh) * 0.5;
+    return abs(r1->x - r2->x) <= delta && abs(r1->y - r2->y) <= delta &&
+           abs(r1->x + r1->w - r2->x - r2->w) <= delta && abs(r1->y + r1->h - r2->y - r2->h) <= delta;
+}
+
+static int oc_partition(const oc_grect* vec, int N, double eps, int* labels) {
+    int (*nodes)[2] = (int (*)[2])malloc(sizeof(int[2]) * (size_t)(N > 0 ? N : 1));
+    int i, j;
+    for (i = 0; i < N; i++) { nodes[i][0] = -1; nodes[i][1] = 0; }
+    for (i = 0; i < N; i++) {
+        int root = i;
+        while (nodes[root][0] >= 0) root = nodes[root][0];
+        for (j = 0; j < N; j++) {
+            if (i == j || !oc_similar(&vec[i], &vec[j], eps)) continue;
+            int root2 = j;
+            while (nodes[root2][0] >= 0) root2 = nodes[root2][0];
+            if (root2 != root) {
+                int rank = nodes[root][1], rank2 = nodes[root2][1];
+                if (rank > rank2)
+                    nodes[root2][0] = root;
+                else {
+                    nodes[root][0] = root2;
+                    nodes[root2][1] += rank == rank2;
+                    root = root2;
+                }
+                int k = j, parent;
+                while ((parent = nodes[k][0]) >= 0) { nodes[k][0] = root; k = parent; }
+                k = i;
+                while ((parent = nodes[k][0]) >= 0) { nodes[k][0] = root; k = parent; }
+            }
+        }
+    }
+    int nclasses = 0;
+    for (i = 0; i < N; i++) {
+        int root = i;
+        while (nodes[root][0] >= 0) root = nodes[root][0];
+        if (nodes[root][1] >= 0) nodes[root][1] = ~nclasses++;
+        labels[i] = ~nodes[root][1];
+    }
+    free(nodes);
+    return nclasses;
+}
+
+/* In place on rects[0..n); weights_out[n] receives the member counts; returns the new count. */
+int oc_group_rectangles(oc_grect* rects, int n, int groupThreshold, double eps, int32_t* weights_out) {
+    if (groupThreshold <= 0 || n == 0) {
+        for (int i = 0; i < n; i++) weights_out[i] = 1;
+        return n;
+    }
+    int* labels = (int*)malloc(sizeof(int) * (size_t)n);
+    int nclasses = oc_partition(rects, n, eps, labels);
+    oc_grect* rrects = (oc_grect*)calloc((size_t)nclasses, sizeof(oc_grect));
+    int* rweights = (int*)calloc((size_t)nclasses, sizeof(int));
+    for (int i = 0; i < n; i++) {
+        int cls = labels[i];
+        rrects[cls].x += rects[i].x; rrects[cls].y += rects[i].y;
+        rrects[cls].w += rects[i].w; rrects[cls].h += rects[i].h;
+        rweights[cls]++;
+    }
+    for (int i = 0; i < nclasses; i++) {
+        oc_grect r = rrects[i];
+        float s = 1.f / rweights[i];
+        rrects[i].x = r.x * s > 2147483647 ? 2147483647 : (int)(r.x * s);
+        rrects[i].y = r.y * s > 2147483647 ? 2147483647 : (int)(r.y * s);
+        rrects[i].w = r.w * s > 2147483647 ? 2147483647 : (int)(r.w * s);
+        rrects[i].h = r.h * s > 2147483647 ? 2147483647 : (int)(r.h * s);
+    }
+    int out = 0;
+    for (int i = 0; i < nclasses; i++) {
+        oc_grect r1 = rrects[i];
+        int n1 = rweights[i], j;
+        if (n1 <= groupThreshold) continue;
+        for (j = 0; j < nclasses; j++) {
+            int n2 = rweights[j];
+            if (j == i || n2 <= groupThreshold) continue;
+            oc_grect r2 = rrects[j];
+            int dx = r2.w * eps > 2147483647 ? 2147483647 : (int)(r2.w * eps);
+            int dy = r2.h * eps > 2147483647 ? 2147483647 : (int)(r2.h * eps);
+            if (i != j && r1.x >= r2.x - dx && r1.y >= r2.y - dy && r1.x + r1.w <= r2.x + r2.w + dx &&
+                r1.y + r1.h <= r2.y + r2.h + dy && (n2 > (3 > n1 ? 3 : n1) || n1 < 3))
+                break;
+        }
+        if (j == nclasses) { rects[out] = r1; weights_out[out] = n1; out++; }
+    }
+    free(labels); free(rrects); free(rweights);
+    return out;
+}

@@ -114,6 +114,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
             env.configure("tile_end", tile_end)
             env.configure("tile_min_windows", minw)
             env.configure("tile_min_lanes", {3: 0, 10: 12, 22: 64, 14: 1, 7: 200}[tile_end])
+            env.configure("tile_repack", {3: "", 10: "3,5", 22: "1,2,3,4,5,6,7,9,11,13,17", 14: "2", 7: "6"}[tile_end])
             for split in ("", "22", "7", "2,4,6,9,12,15,18"):
                 env.configure("pass_split", split)
                 r = env.detect(c, frames, p)
@@ -126,6 +127,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("tile_end", 8)
         env.configure("tile_min_windows", 1024)
         env.configure("tile_min_lanes", 0)
+        env.configure("tile_repack", "3,5")
 
 
 def test_scale_mask_partitions_the_result(env, cascades):
@@ -177,8 +179,40 @@ def test_empty_and_too_small_inputs(env, cascades):
     from clfacedetection_amd import VjError
     with pytest.raises(VjError):
         env.detect(c, [np.zeros((40, 40), np.uint8), np.zeros((41, 40), np.uint8)], default_params())
-    with pytest.raises(VjError):
-        env.detect(c, np.zeros((40, 40), np.uint8), default_params(min_neighbors=3))
+
+
+@pytest.mark.parametrize("min_neighbors", [1, 2, 3])
+def test_min_neighbors_grouping(env, oracle, cascades, min_neighbors):
+    """BASELINE config 1 shape: 640x480, frontalface_default, minNeighbors = 3 — raw candidates from the
+    HIP path, grouped on the host as the reference does (clod.cpp:1325-1326)."""
+    c, a = cascades("frontalface_default")
+    # a frame with a planted cluster of detections: tile one detected window of a noise frame
+    frames = synth.batch(3, 480, 640, seed0=120, kinds=("noise",))
+    raw = env.detect(c, frames, default_params())
+    got = clodDetectObjects(frames, c, env, (0, 0), (0, 0), min_neighbors, 0, True)
+    want = []
+    for f in range(len(frames)):
+        ro, _ = oracle.detect(a, frames[f])
+        xywh = np.stack([ro[k] for k in ("x", "y", "w", "h")], 1) if len(ro) else np.zeros((0, 4), np.int32)
+        g, w = oracle.group_rectangles(xywh, max(min_neighbors, 1))
+        want += [(int(r[0]), int(r[1]), int(r[2]), int(r[3]), int(n), f) for r, n in zip(g, w)]
+    assert [(int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"]), int(r["weight"]), int(r["frame"])) for r in got.rects] == want
+    assert len(got.rects) <= len(raw.rects)
+
+
+def test_grouping_of_dense_detections(env, oracle, cascades):
+    """Force many overlapping raw candidates (an all-stages-pass image does not exist, so re-use raw
+    detections of several noise frames as one frame's list) and group them through the C ABI."""
+    from clfacedetection_amd import group_rectangles
+    c, a = cascades("frontalface_alt")
+    frames = synth.batch(6, 360, 480, seed0=900, kinds=("noise",))
+    raw = env.detect(c, frames, default_params()).rects.copy()
+    raw["frame"] = 0
+    raw = np.concatenate([raw] * 3)          # every rect three times: classes of >= 3 members
+    got = group_rectangles(raw, 2)
+    g, w = oracle.group_rectangles(np.stack([raw[k] for k in ("x", "y", "w", "h")], 1), 2)
+    assert np.array_equal(np.stack([got[k] for k in ("x", "y", "w", "h")], 1), g)
+    assert got["weight"].astype(int).tolist() == w.tolist() and len(got) > 0
 
 
 def test_native_library_is_the_one_running(env):

@@ -46,6 +46,14 @@ if "ab" in what:
                 out.append(f"{'tile' if classes != '0,0,0' else 'glob'} {r.passes[0][2]:.3f} ms {ev / r.passes[0][2] / 1e6:.1f} Gev/s")
             print(f"scale {k} s={scales[k].scale:.2f} stages[0,{sp}) windows={rc.windows}: " + " | ".join(out), flush=True)
     env.configure("tile_classes_kb", "36,64,140"); env.configure("pass_split", ""); env.configure("tile_min_lanes", 0)
+if "repack" in what:
+    for rp in ("", "3,5", "2,3,4,5,6,7", "3,5,6,7"):
+        env.configure("tile_repack", rp)
+        for sp, te in (("5,8", 8), ("5,8,11", 11), ("5,8,11,14", 14), ("5,8,10,12", 12), ("3,5,8,11", 11), ("5,10", 10)):
+            env.configure("pass_split", sp); env.configure("tile_end", te)
+            r = run(default_params())
+            print(f"repack={rp!r} split={sp!r} tile_end={te}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("tile_repack", "3,5"); env.configure("pass_split", ""); env.configure("tile_end", 8)
 if "accept" in what:
     for classes in ("36,64,140", "36,64,100", "36,72,0", "40,80,0", "52,80,0", "52,80,140"):
         env.configure("tile_classes_kb", classes)
