@@ -86,7 +86,10 @@ struct vj_env {
     hipStream_t stream = nullptr;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t pass_ev[VJ_MAX_PASSES + 1] = {};
-    hipEvent_t launch_ev[VJ_MAX_LAUNCHES + 1] = {};
+    hipEvent_t launch_ev[2 * VJ_MAX_LAUNCHES] = {};   // start/stop per launch
+    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
+    hipStream_t stream2 = nullptr;   // second chain of the first part of the cascade
+    int concurrent = 0;   // measured: no gain (tile workgroups fill the LDS, the two chains serialise anyway)
     char name[256] = "";
     int n_cu = 0;
     // image buffers
@@ -565,8 +568,9 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.tile_repack_mask = e->tile_repack_mask;
         int launches = 0;
         std::vector<vj_launch> linfo;
-        auto begin_launch = [&](int kind, int cls, uint32_t sb, uint32_t se, uint32_t lds) -> int {
-            if (linfo.size() < VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(e->launch_ev[linfo.size()], e->stream));
+        // every launch is bracketed by its own pair of events on the stream it runs on
+        auto begin_launch = [&](int kind, int cls, uint32_t sb, uint32_t se, uint32_t lds, hipStream_t st) -> int {
+            if (linfo.size() < VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(e->launch_ev[2 * linfo.size()], st));
             vj_launch li;
             memset(&li, 0, sizeof(li));
             li.kind = kind;
@@ -582,51 +586,94 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             linfo.push_back(li);
             return VJ_OK;
         };
+        auto end_launch = [&](hipStream_t st) -> int {
+            if (linfo.size() <= VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(e->launch_ev[2 * linfo.size() - 1], st));
+            return VJ_OK;
+        };
+        auto queue_args = [&](size_t ps) {
+            CascadeArgs qa = ca;
+            qa.stage_begin = pl->pass_bounds[ps];
+            qa.stage_end = pl->pass_bounds[ps + 1];
+            const bool last = ps + 1 == n_pass;
+            // pass ps reads queue ps (filled by pass ps-1 and by tiles that left at this boundary)
+            // and appends its survivors to queue ps+1
+            qa.q_in = (const QEntry*)e->d_q[ps].p;
+            qa.q_in_count = d_qcount[ps];
+            qa.q_out = last ? nullptr : (QEntry*)e->d_q[ps + 1].p;
+            qa.q_out_count = last ? nullptr : d_qcount[ps + 1];
+            return qa;
+        };
         if (ca.n_units + ca.n_tile_units > 0) {
-            for (size_t ps = 0; ps < n_pass; ++ps) {
-                ca.stage_begin = pl->pass_bounds[ps];
-                ca.stage_end = pl->pass_bounds[ps + 1];
-                const bool last = ps + 1 == n_pass;
-                // pass ps reads queue ps (filled by pass ps-1 and by tile waves that left at
-                // this boundary) and appends its survivors to queue ps+1
-                ca.q_in = (const QEntry*)e->d_q[ps].p;
-                ca.q_in_count = d_qcount[ps];
-                ca.q_out = last ? nullptr : (QEntry*)e->d_q[ps + 1].p;
-                ca.q_out_count = last ? nullptr : d_qcount[ps + 1];
-                if (ps < VJ_MAX_PASSES) HIP_TRY(hipEventRecord(e->pass_ev[ps], e->stream));
-                int hrc = 0;
-                if (ps == 0) {
-                    for (uint32_t cls = 0; cls < TILE_CLASSES && !hrc; ++cls) {
-                        const uint32_t n_cls = pl->class_first[cls + 1] - pl->class_first[cls];
-                        if (!n_cls) continue;
-                        CascadeArgs ta = ca;
-                        ta.tile_units = (const UnitDev*)pl->d_tile_units.p + pl->class_first[cls];
-                        ta.n_tile_units = n_cls;
-                        ta.tile_lds_bytes = pl->class_lds[cls];
-                        // workgroups per CU: what the LDS allows (160 KiB per CU), at most 4 x 8 waves
-                        const int per_cu = std::max(1, std::min(4, (int)(160u * 1024u / ta.tile_lds_bytes)));
-                        const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf,
-                                                               (uint64_t)e->n_cu * (uint64_t)per_cu);
-                        const uint32_t deepest = std::min<uint32_t>((uint32_t)pl->stages.size(),
-                                                                    std::max<uint32_t>(ca.tile_end, pl->pass_bounds[1]));
-                        if ((rc = begin_launch(VJ_LAUNCH_TILE, (int)cls, 0, deepest, ta.tile_lds_bytes))) return rc;
-                        hrc = launch_cascade_tile_pass(ta, pl->trees, count, std::max(1, tb), e->stream);
-                    }
-                }
-                if (!hrc && (ps > 0 || ca.n_units > 0) &&
-                    (rc = begin_launch(ps == 0 ? VJ_LAUNCH_GRID : VJ_LAUNCH_QUEUE, 0, ca.stage_begin, ca.stage_end, 0)))
-                    return rc;
-                if (!hrc && (ps > 0 || ca.n_units > 0))
-                    hrc = launch_cascade_pass(ca, ps == 0, pl->trees, last, count, pl->general, n_blocks, e->stream);
-                if (hrc) {
-                    set_error("cascade launch failed: %s", hipGetErrorString((hipError_t)hrc));
-                    return VJ_ERR_HIP;
-                }
-                ++launches;
+            int hrc = 0;
+            // Two chains share the first part of the cascade and run CONCURRENTLY on two streams:
+            //   A (e->stream) : the LDS-tile launches (LDS-bound)
+            //   B (e->stream2): the global-gather first pass and the queue passes that only it feeds
+            //                   (texture-address-bound) — every pass that begins before the stage at
+            //                   which tiles hand over (tiles leave at one boundary when tile_min_lanes = 0)
+            // then B joins A and the remaining queue passes run on A.
+            const uint32_t handover = pl->general ? 0u : std::max<uint32_t>(ca.tile_end, pl->pass_bounds[1]);
+            size_t first_joint_pass = 1;
+            if (e->tile_min_lanes == 0)
+                while (first_joint_pass < n_pass && pl->pass_bounds[first_joint_pass] < handover) ++first_joint_pass;
+            const bool two_streams = e->concurrent && ca.n_tile_units > 0 && ca.n_units > 0;
+            hipStream_t sB = two_streams ? e->stream2 : e->stream;
+            if (two_streams) {
+                HIP_TRY(hipEventRecord(e->fork_ev, e->stream));
+                HIP_TRY(hipStreamWaitEvent(e->stream2, e->fork_ev, 0));
             }
+            HIP_TRY(hipEventRecord(e->pass_ev[0], e->stream));
+            // chain A: tile launches
+            for (uint32_t cls = 0; cls < TILE_CLASSES && !hrc && ca.n_tile_units > 0; ++cls) {
+                const uint32_t n_cls = pl->class_first[cls + 1] - pl->class_first[cls];
+                if (!n_cls) continue;
+                CascadeArgs ta = ca;
+                ta.tile_units = (const UnitDev*)pl->d_tile_units.p + pl->class_first[cls];
+                ta.n_tile_units = n_cls;
+                ta.tile_lds_bytes = pl->class_lds[cls];
+                // workgroups per CU: what the LDS allows (160 KiB per CU), at most 4 x 8 waves
+                const int per_cu = std::max(1, std::min(4, (int)(160u * 1024u / ta.tile_lds_bytes)));
+                const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
+                const uint32_t deepest = std::min<uint32_t>((uint32_t)pl->stages.size(), handover);
+                if ((rc = begin_launch(VJ_LAUNCH_TILE, (int)cls, 0, deepest, ta.tile_lds_bytes, e->stream))) return rc;
+                hrc = launch_cascade_tile_pass(ta, pl->trees, count, std::max(1, tb), e->stream);
+                if ((rc = end_launch(e->stream))) return rc;
+            }
+            // chain B: grid pass, then the queue passes fed by it alone
+            if (!hrc && ca.n_units > 0) {
+                CascadeArgs ga = queue_args(0);
+                if ((rc = begin_launch(VJ_LAUNCH_GRID, 0, ga.stage_begin, ga.stage_end, 0, sB))) return rc;
+                hrc = launch_cascade_pass(ga, true, pl->trees, n_pass == 1, count, pl->general, n_blocks, sB);
+                if ((rc = end_launch(sB))) return rc;
+                for (size_t ps = 1; ps < first_joint_pass && !hrc; ++ps) {
+                    CascadeArgs qa = queue_args(ps);
+                    if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, sB))) return rc;
+                    hrc = launch_cascade_pass(qa, false, pl->trees, ps + 1 == n_pass, count, false, n_blocks, sB);
+                    if ((rc = end_launch(sB))) return rc;
+                }
+            } else {
+                first_joint_pass = 1;
+            }
+            if (two_streams) {
+                HIP_TRY(hipEventRecord(e->join_ev, e->stream2));
+                HIP_TRY(hipStreamWaitEvent(e->stream, e->join_ev, 0));
+            }
+            for (size_t ps = 1; ps < n_pass && ps < VJ_MAX_PASSES && ps <= first_joint_pass; ++ps)
+                HIP_TRY(hipEventRecord(e->pass_ev[ps], e->stream));
+            // joint passes
+            for (size_t ps = first_joint_pass; ps < n_pass && !hrc; ++ps) {
+                if (ps > first_joint_pass && ps < VJ_MAX_PASSES) HIP_TRY(hipEventRecord(e->pass_ev[ps], e->stream));
+                CascadeArgs qa = queue_args(ps);
+                if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, e->stream))) return rc;
+                hrc = launch_cascade_pass(qa, false, pl->trees, ps + 1 == n_pass, count, false, n_blocks, e->stream);
+                if ((rc = end_launch(e->stream))) return rc;
+            }
+            if (hrc) {
+                set_error("cascade launch failed: %s", hipGetErrorString((hipError_t)hrc));
+                return VJ_ERR_HIP;
+            }
+            launches = (int)n_pass;
         }
         if (n_pass <= VJ_MAX_PASSES && launches) HIP_TRY(hipEventRecord(e->pass_ev[n_pass], e->stream));
-        if (linfo.size() <= VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(e->launch_ev[linfo.size()], e->stream));
         HIP_TRY(hipEventRecord(e->ev[3], e->stream));
         // read back the counters block
         HIP_TRY(hipMemcpyAsync(e->h_pinned, e->d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
@@ -658,7 +705,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         if (linfo.size() <= VJ_MAX_LAUNCHES) {
             for (size_t i = 0; i < linfo.size(); ++i) {
                 float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, e->launch_ev[i], e->launch_ev[i + 1]));
+                HIP_TRY(hipEventElapsedTime(&ms, e->launch_ev[2 * i], e->launch_ev[2 * i + 1]));
                 const float prev = tm->launch[i].ms;
                 tm->launch[i] = linfo[i];
                 tm->launch[i].ms = prev + ms;
@@ -720,6 +767,9 @@ int vj_env_create(int device_index, vj_env** out) {
     for (auto& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
     for (auto& ev : e->pass_ev) HIP_TRY(hipEventCreate(&ev));
     for (auto& ev : e->launch_ev) HIP_TRY(hipEventCreate(&ev));
+    HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
     e->h_pinned_bytes = 8192;
     HIP_TRY(hipHostMalloc(&e->h_pinned, e->h_pinned_bytes, hipHostMallocDefault));
     if (const char* s = getenv("VJ_BLOCKS_PER_CU")) e->blocks_per_cu = std::max(1, atoi(s));
@@ -752,6 +802,9 @@ void vj_env_destroy(vj_env* e) {
         if (ev) (void)hipEventDestroy(ev);
     for (auto& ev : e->launch_ev)
         if (ev) (void)hipEventDestroy(ev);
+    if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
+    if (e->join_ev) (void)hipEventDestroy(e->join_ev);
+    if (e->stream2) (void)hipStreamDestroy(e->stream2);
     if (e->stream) (void)hipStreamDestroy(e->stream);
     delete e;
 }
@@ -823,6 +876,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
                                                   : e->tile_min_lanes) = v;
         HIP_TRY(hipStreamSynchronize(e->stream));
         drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "concurrent") == 0) {  // 1: tile launches and the global first pass overlap on two streams
+        e->concurrent = atoi(value) != 0;
         return VJ_OK;
     }
     if (strcmp(key, "tile_repack") == 0) {  // "3,5": stages before which tiles re-pack ("" = never)

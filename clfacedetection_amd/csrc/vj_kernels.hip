@@ -521,17 +521,23 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
         }
     } else {
         kptr<uint32_t> counts = as_k(a.q_in_count);
+        // chunk size: spread this pass's windows over all waves (a wave works through its chunk
+        // serially, ~1 us per stump, so late passes with few windows want small chunks), in
+        // whole 64-lane groups, at most the LDS queue capacity
+        uint32_t total = 0;
+        for (uint32_t slot = 0; slot < a.n_scales; ++slot) total += counts[slot];
+        const uint32_t chunk = min((uint32_t)UNIT_WINDOWS, max(64u, ((total / a.total_waves + 63u) / 64u) * 64u));
         uint32_t start = 0;  // chunks of all previous scales; chunk c of scale k is virtual unit start + c
         for (uint32_t slot = 0; slot < a.n_scales; ++slot) {
             const uint32_t cnt = counts[slot];
-            const uint32_t n_chunks = (cnt + UNIT_WINDOWS - 1u) / UNIT_WINDOWS;
+            const uint32_t n_chunks = (cnt + chunk - 1u) / chunk;
             const uint32_t q_base = scales[slot].q_base;
             const uint32_t table_first = scales[slot].table_first;
             // first chunk of this scale owned by this wave: start + c == rank (mod total_waves)
             uint32_t c = (rank + a.total_waves - start % a.total_waves) % a.total_waves;
             for (; c < n_chunks; c += a.total_waves) {
-                const uint32_t c0 = c * UNIT_WINDOWS;
-                const uint32_t n = min(cnt - c0, (uint32_t)UNIT_WINDOWS);
+                const uint32_t c0 = c * chunk;
+                const uint32_t n = min(cnt - c0, chunk);
                 for (uint32_t i = lane; i < n; i += 64u) q[i] = a.q_in[(size_t)q_base + c0 + i];
                 __builtin_amdgcn_wave_barrier();
                 run_stages_linear<TREES, LAST, COUNT>(a, img, q, n, slot, table_first, q_base, lane, a.stage_begin);

@@ -3,6 +3,11 @@ import sys
 
 import pytest
 
+try:    # PyTorch-ROCm bundles its own libamdhip64 (same soname as /opt/rocm's): whichever is loaded
+    import torch  # noqa: F401  first serves the whole process, and torch cannot initialise on top of
+except Exception:  # the system runtime — so torch goes first ("Sharing a process with PyTorch")
+    torch = None
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)

@@ -106,6 +106,10 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
             r = env.detect(c, frames, p)
             assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, b
         env.configure("blocks_per_cu", 8)
+        env.configure("concurrent", 1)
+        r = env.detect(c, frames, p)
+        assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
+        env.configure("concurrent", 0)
         # LDS-tile path off / small / large tiles / shallow / deep: the tile and the
         # global-gather paths agree bit for bit
         for classes, tile_end, minw in (("0,0,0", 10, 1024), ("24,40,60", 3, 1024), ("36,64,140", 10, 1024),

@@ -54,6 +54,20 @@ if "repack" in what:
             r = run(default_params())
             print(f"repack={rp!r} split={sp!r} tile_end={te}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{l['ms']:.1f}" for l in r.launches), flush=True)
     env.configure("tile_repack", "3,5"); env.configure("pass_split", ""); env.configure("tile_end", 8)
+if "conc" in what:
+    for conc in (0, 1):
+        env.configure("concurrent", conc)
+        for sp, te in (("5,8", 8), ("5,8,12,16", 8), ("4,8", 8), ("5,10", 10), ("3,5,8", 8)):
+            env.configure("pass_split", sp); env.configure("tile_end", te)
+            r = run(default_params())
+            print(f"concurrent={conc} split={sp!r} tile_end={te}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("concurrent", 0); env.configure("pass_split", ""); env.configure("tile_end", 8)
+if "b64" in what:
+    for sp, te in (("5,8", 8), ("5,8,12", 8), ("5,8,11,14,17", 8), ("5,8,10,12,14,17", 8), ("4,6,8,10,12,15,18", 8), ("5,10", 10), ("5,10,13,16", 10), ("5,9,12,15,18", 9), ("5,7,9,11,13,16", 7)):
+        env.configure("pass_split", sp); env.configure("tile_end", te)
+        r = run(default_params(), 2)
+        print(f"split={sp!r} tile_end={te}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("pass_split", ""); env.configure("tile_end", 8)
 if "accept" in what:
     for classes in ("36,64,140", "36,64,100", "36,72,0", "40,80,0", "52,80,0", "52,80,140"):
         env.configure("tile_classes_kb", classes)
