@@ -81,6 +81,10 @@ constexpr int TILE_W = 64;           // windows per tile row (= lanes of a wave)
 constexpr int TILE_WAVE_CAP = 256;    // windows (= LDS queue entries) per wave of the tile kernel
 constexpr int TILE_CLASSES = 3;       // LDS size classes, one launch each
 constexpr int TILE_LDS_HEADER = (TILE_WAVES * TILE_WAVE_CAP * 2 + 16) * 4;  // queues + per-wave counts, bytes
+constexpr int TILE_SP_MAX_WINDOWS = 512;  // windows a tile may carry into the stump-parallel finish (one per thread)
+constexpr int TILE_SP_GROUP = 44;         // windows whose stump values fit the value buffer at a time
+constexpr int TILE_SP_BLOCK = 64;         // stumps evaluated per round and window (= lanes of a wave)
+constexpr int TILE_SP_FIELDS = 14;        // dwords of a node record kept in the LDS copy of a stage's table
 
 struct CascadeArgs {
     const uint32_t* sum;        // batch sum images, frame f at f * frame_elems
@@ -114,6 +118,12 @@ struct CascadeArgs {
     uint32_t  tile_end;                     // deepest stage a tile launch may enter
     uint32_t  tile_min_lanes;               // leave at a pass boundary when the whole tile has fewer survivors
     unsigned long long tile_repack_mask;    // bit s: re-pack the tile's survivors across its waves before stage s
+    // Stump-parallel finish (stump cascades): once a tile is down to <= TILE_SP_MAX_WINDOWS windows at a
+    // re-pack point at or after tile_sp_begin, its 512 lanes evaluate (window, stump) pairs in parallel
+    // and one lane per window adds the stump values in cascade order — through the last stage.
+    uint32_t  tile_sp_begin;                // >= number of stages: disabled
+    uint32_t  tile_sp_pad;                  // dwords of LDS reserved for one block of node records (0 = off)
+    uint32_t  tile_sp_max;                  // enter the finish when at most this many windows are left (<= 512)
     DetEntry* det;              // detections (last pass)
     uint32_t* det_count;
     uint32_t  det_cap;

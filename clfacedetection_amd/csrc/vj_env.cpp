@@ -64,6 +64,7 @@ struct Plan {
     uint32_t class_first[TILE_CLASSES + 1] = {};  // tile_units range of each class
     uint32_t class_lds[TILE_CLASSES] = {};        // dynamic LDS bytes of each class launch
     uint32_t tile_end = 0;                        // stage at which the tile launches stop
+    uint32_t sp_pad = 0;                          // LDS pitch of the stump-parallel stage table (0 = off)
     std::vector<uint32_t> pass_bounds;       // stage indices: pass p runs [b[p], b[p+1])
     uint64_t windows_per_frame = 0;
     uint32_t frame_elems = 0;
@@ -103,12 +104,16 @@ struct vj_env {
     std::map<PlanKey, std::unique_ptr<Plan>> plans;
     // tunables (env vars, read once)
     int blocks_per_cu = 8;
-    int tile_class_kb[TILE_CLASSES] = {36, 64, 140};  // image-tile LDS budget per class; all 0 disables the tile path
+    int tile_class_kb[TILE_CLASSES] = {-3, -2, -1};  // image-tile LDS budget per class in KiB; -k = what lets k
+                                                     // workgroups share a CU's 160 KiB; all 0 disables the tile path
     int tile_min_windows = 1024;  // a class is acceptable for a scale when a tile holds at least this many windows
-    int tile_accept_windows = 512;  // scales whose best tile holds fewer windows stay on the global-gather path
-    int tile_end = 8;             // tile launches never enter a pass that begins at or beyond this stage
+    int tile_max_dwords_per_window = 600;  // staging a tile must stay far cheaper than gathering its windows from L2
+    int tile_accept_windows = 256;  // scales whose best tile holds fewer windows stay on the global-gather path
+    int tile_end = 12;            // tile launches never enter a pass that begins at or beyond this stage
     int tile_min_lanes = 0;       // a tile leaves at a pass boundary when fewer windows than this survive in it
-    unsigned long long tile_repack_mask = (1ull << 3) | (1ull << 5);  // stages before which a tile re-packs its survivors
+    unsigned long long tile_repack_mask = 0x3ffffcull;  // stages (2..21) before which a tile re-packs its survivors
+    int tile_sp_begin = 4;        // first stage at which a tile may switch to the stump-parallel finish (>= 64: never)
+    int tile_sp_max = 192;        // ... once at most this many of its windows survive
     std::vector<int> split_override;
 };
 
@@ -139,12 +144,12 @@ static std::vector<uint32_t> default_pass_bounds(const vj_cascade& c, const Stag
         for (int v : override_)
             if (v > (int)b.back() && v < (int)n) b.push_back((uint32_t)v);
     } else {
-        // cut after roughly 110 and 250 cumulative nodes (frontalface_alt: 5 | 8), measured best
-        // on 1080p batches: [0,5) global first pass, tiles to 8, one re-packed queue pass after
-        const uint32_t cuts[2] = {110, 250};
+        // cut after roughly 110, 250 and 600 cumulative nodes (frontalface_alt: 5 | 8 | 12), measured
+        // best on 1080p batches: [0,5) global first pass, re-packed queue passes after it
+        const uint32_t cuts[3] = {110, 250, 600};
         uint32_t acc = 0;
         int ci = 0;
-        for (uint32_t s = 0; s < n && ci < 2; ++s) {
+        for (uint32_t s = 0; s < n && ci < 3; ++s) {
             acc += prog.n_nodes[s];
             if (acc >= cuts[ci] && s + 1 < n) {
                 b.push_back(s + 1);
@@ -210,6 +215,10 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     const uint32_t stride = (uint32_t)W + 1u;
     const size_t n_nodes = c.nodes.size();
 
+    // stump-parallel finish: LDS room for one block of node records, field-major (dwords)
+    if (!pl->trees && !pl->general && e->tile_sp_begin < (int)c.stages.size())
+        pl->sp_pad = ((uint32_t)TILE_SP_FIELDS * (TILE_SP_BLOCK + 1u) + 3u) & ~3u;
+    const uint32_t tile_header_bytes = TILE_LDS_HEADER + pl->sp_pad * 4u;
     std::vector<NodeRec> table;
     for (const vj_scale_info& si : pl->scales_all) {
         if (!si.accepted || si.nx <= 0 || si.ny <= 0) continue;
@@ -268,7 +277,9 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
             static const uint32_t kTw[] = {64, 48, 32, 24, 16, 12, 8}, kTh[] = {32, 24, 16, 12, 8, 6, 4};
             uint32_t best_cls = TILE_CLASSES, best_n = 0, b_tw = 0, b_th = 0, b_pitch = 0, b_rows = 0;
             for (uint32_t cls = 0; cls < TILE_CLASSES && best_n < (uint32_t)e->tile_min_windows; ++cls) {
-                const uint64_t budget = (uint64_t)e->tile_class_kb[cls] * 1024u;
+                const int kb = e->tile_class_kb[cls];
+                const uint64_t budget = kb < 0 ? (160u * 1024u / (uint32_t)(-kb) - tile_header_bytes) & ~63ull
+                                               : std::min<uint64_t>((uint64_t)kb * 1024u, 160u * 1024u - tile_header_bytes);
                 for (uint32_t tw : kTw)
                     for (uint32_t th : kTh) {
                         const uint32_t nwt = tw * th;
@@ -278,7 +289,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                         const uint32_t rows = (uint32_t)std::ceil((double)(th - 1) * (double)si.step) + 3u + reach_y;
                         if ((uint64_t)pitch * rows * 4u > budget) continue;
                         // staging a tile must stay far cheaper than gathering its windows from L2
-                        if ((uint64_t)pitch * rows > 600ull * nwt) continue;
+                        if ((uint64_t)pitch * rows > (uint64_t)e->tile_max_dwords_per_window * nwt) continue;
                         best_cls = cls; best_n = nwt; b_tw = tw; b_th = th; b_pitch = pitch; b_rows = rows;
                     }
             }
@@ -339,7 +350,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                     pl->tile_units.push_back(UnitDev{slot, ix0 | (iy0 << 16), 0, 0});
             pl->class_lds[cls] = std::max(pl->class_lds[cls], sd.tile_pitch * sd.tile_rows * 4u);
         }
-        if (pl->class_lds[cls]) pl->class_lds[cls] += TILE_LDS_HEADER;
+        if (pl->class_lds[cls]) pl->class_lds[cls] += tile_header_bytes;
     }
     pl->class_first[TILE_CLASSES] = (uint32_t)pl->tile_units.size();
 
@@ -566,6 +577,9 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.tile_end = (uint32_t)e->tile_end;
         ca.tile_min_lanes = (uint32_t)e->tile_min_lanes;
         ca.tile_repack_mask = e->tile_repack_mask;
+        ca.tile_sp_begin = pl->sp_pad ? (uint32_t)e->tile_sp_begin : 0xffffffffu;
+        ca.tile_sp_pad = pl->sp_pad;
+        ca.tile_sp_max = (uint32_t)std::min(e->tile_sp_max, (int)TILE_SP_MAX_WINDOWS);
         int launches = 0;
         std::vector<vj_launch> linfo;
         // every launch is bracketed by its own pair of events on the stream it runs on
@@ -852,7 +866,7 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         for (int i = 0; i < TILE_CLASSES && *q; ++i) {
             char* endp;
             v[i] = (int)strtol(q, &endp, 10);
-            if (endp == q || v[i] < 0 || v[i] > 140) {
+            if (endp == q || v[i] < -4 || v[i] > 140) {
                 set_error("tile_classes_kb: expected up to %d values in [0,140]", TILE_CLASSES);
                 return VJ_ERR_ARG;
             }
@@ -863,14 +877,25 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         drop_plans(e);
         return VJ_OK;
     }
+    if (strcmp(key, "tile_sp_max") == 0) {
+        e->tile_sp_max = std::max(0, std::min(atoi(value), (int)TILE_SP_MAX_WINDOWS));
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_sp_begin") == 0) {
+        e->tile_sp_begin = std::max(0, atoi(value));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);   // the LDS layout of the tile launches depends on it
+        return VJ_OK;
+    }
     if (strcmp(key, "tile_min_windows") == 0 || strcmp(key, "tile_end") == 0 || strcmp(key, "tile_min_lanes") == 0 ||
-        strcmp(key, "tile_accept_windows") == 0) {
+        strcmp(key, "tile_accept_windows") == 0 || strcmp(key, "tile_max_dwords_per_window") == 0) {
         const int v = atoi(value);
-        if (v < 0 || v > 4096) {
+        if (v < 0 || v > 65536) {
             set_error("%s out of range", key);
             return VJ_ERR_ARG;
         }
-        (strcmp(key, "tile_min_windows") == 0      ? e->tile_min_windows
+        (strcmp(key, "tile_max_dwords_per_window") == 0 ? e->tile_max_dwords_per_window
+         : strcmp(key, "tile_min_windows") == 0      ? e->tile_min_windows
          : strcmp(key, "tile_end") == 0           ? e->tile_end
          : strcmp(key, "tile_accept_windows") == 0 ? e->tile_accept_windows
                                                   : e->tile_min_lanes) = v;

@@ -556,12 +556,130 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
 // its rw rows of windows — but gathers the rectangle corners from LDS instead of
 // through the texture-address unit.  Survivors leave through the same global queues
 // as the global-gather pass, as {global byte offset, variance}.
+
+// Stump-parallel finish of a tile (stump cascades).  lds_q[0..T) holds the tile's T <= TILE_SP_MAX_WINDOWS
+// surviving windows.  Per stage: the stage's node records are copied to LDS field-major; wave w of each
+// round takes one window and its 64 lanes take 64 consecutive stumps — every (window, stump) value
+// alpha[rect_sum >= thr * var] is independent — and store the values; then lane t of wave 0 adds window
+// t's values IN STUMP ORDER (stage_sum += alpha, clod.cl:81), exactly the sequence a single lane would
+// have produced, compares with the stage threshold and wave 0 compacts the survivors.  Replaces the
+// serial tail (one thin wave, ~300 cycles per stump) of the late stages.
+template <bool COUNT>
+__device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, const LdsImg& img,
+                                                        const uint32_t* table /* the scale's tile table, global */,
+                                                        QEntry* lds_q, float* lds_val, uint32_t* lds_tab,
+                                                        uint32_t* lds_cnt, uint32_t T, uint32_t st_begin,
+                                                        uint32_t n_stages, uint32_t lane, uint32_t wib) {
+    kptr<StageDev> stages = as_k(a.stages);
+    const uint32_t tid = wib * 64u + lane;
+    constexpr uint32_t PITCH = TILE_SP_BLOCK + 1u;   // odd pitch: column reads/writes hit distinct banks
+    constexpr uint32_t NT = TILE_WAVES * 64u;
+    // Blocks of <= 64 consecutive stumps, balanced inside each stage.  The records of block k+1 are
+    // fetched from global memory into registers (2 dwords per thread) while block k is evaluated.
+    uint32_t s = st_begin;
+    uint32_t S = stages[s].n_nodes, first_node = stages[s].first_node;
+    uint32_t n_blocks = (S + TILE_SP_BLOCK - 1u) / TILE_SP_BLOCK, b = 0, jb = 0;
+    uint32_t jn = S / n_blocks + (0u < S % n_blocks ? 1u : 0u);
+    uint32_t pre0 = 0, pre1 = 0;
+    {
+        const uint32_t* src = table + (size_t)(first_node + jb) * 16u;
+        if (tid < jn * 16u) pre0 = src[tid];
+        if (tid + NT < jn * 16u) pre1 = src[tid + NT];
+    }
+    float sum = 0.0f;   // thread t < T owns window t
+    if (COUNT && tid == 0) atomicAdd(a.stage_entered + s, (unsigned long long)T);
+    while (true) {
+        // 1. this block's node records -> LDS, field-major: lane j reads field f at lds_tab[f * PITCH + j]
+        if (tid < jn * 16u && (tid & 15u) < (uint32_t)TILE_SP_FIELDS) lds_tab[(tid & 15u) * PITCH + (tid >> 4)] = pre0;
+        if (tid + NT < jn * 16u && (tid & 15u) < (uint32_t)TILE_SP_FIELDS)
+            lds_tab[(tid & 15u) * PITCH + ((tid + NT) >> 4)] = pre1;
+        __syncthreads();
+        // next block (possibly of the next stage — harmless if this stage turns out to be the last)
+        uint32_t ns = s, nb = b + 1u, njb = jb + jn, nS = S, nfirst = first_node, nnb = n_blocks;
+        if (nb == n_blocks) {
+            ns = s + 1u;
+            nb = 0u;
+            njb = 0u;
+            if (ns < n_stages) {
+                nS = stages[ns].n_nodes;
+                nfirst = stages[ns].first_node;
+                nnb = (nS + TILE_SP_BLOCK - 1u) / TILE_SP_BLOCK;
+            }
+        }
+        const uint32_t njn = nS / nnb + (nb < nS % nnb ? 1u : 0u);
+        if (ns < n_stages) {
+            const uint32_t* src = table + (size_t)(nfirst + njb) * 16u;
+            if (tid < njn * 16u) pre0 = src[tid];
+            if (tid + NT < njn * 16u) pre1 = src[tid + NT];
+        }
+        // 2./3. groups of TILE_SP_GROUP windows share the value buffer: wave w handles windows
+        // gb + w, gb + w + 8, ... (lane j = stump jb + j), then thread t < T adds window t's values
+        // in stump order (stage_sum += alpha); loads issued 8 at a time
+        for (uint32_t gb = 0; gb < T; gb += TILE_SP_GROUP) {
+            const uint32_t gcount = min((uint32_t)TILE_SP_GROUP, T - gb);
+            for (uint32_t w = wib; w < gcount; w += TILE_WAVES) {
+                if (lane < jn) {
+                    const QEntry e = lds_q[gb + w];   // broadcast
+                    NodeRecDev r;
+#pragma unroll
+                    for (int f = 0; f < TILE_SP_FIELDS; ++f) r[f] = lds_tab[f * PITCH + lane];
+                    r[14] = 0u;
+                    r[15] = 0u;
+                    const float norm_threshold = __uint_as_float(r[11]) * e.var;
+                    const float rect_sum = node_rect_sum(img, r, e.off);
+                    lds_val[w * PITCH + lane] = (rect_sum >= norm_threshold) ? __uint_as_float(r[13]) : __uint_as_float(r[12]);
+                }
+            }
+            __syncthreads();
+            if (tid >= gb && tid < gb + gcount) {
+                const float* vrow = lds_val + (tid - gb) * PITCH;
+                uint32_t k = 0;
+                for (; k + 8u <= jn; k += 8u) {
+                    const float v0 = vrow[k], v1 = vrow[k + 1], v2 = vrow[k + 2], v3 = vrow[k + 3];
+                    const float v4 = vrow[k + 4], v5 = vrow[k + 5], v6 = vrow[k + 6], v7 = vrow[k + 7];
+                    sum += v0; sum += v1; sum += v2; sum += v3; sum += v4; sum += v5; sum += v6; sum += v7;
+                }
+                for (; k < jn; ++k) sum += vrow[k];
+            }
+            if (gb + TILE_SP_GROUP < T) __syncthreads();   // the value buffer is reused by the next group
+        }
+        const bool stage_done = b + 1u == n_blocks;
+        if (stage_done) {
+            // 4. survivors: thread t < T holds window t's verdict; compact lds_q across the waves
+            const float threshold = stages[s].threshold;
+            const bool pass = tid < T && sum >= threshold;
+            const QEntry e = lds_q[tid < T ? tid : 0u];
+            const unsigned long long mask = __ballot(pass);
+            if (lane == 0) lds_cnt[1u + wib] = (uint32_t)__popcll(mask);
+            __syncthreads();   // every entry is in registers, every wave's count is published
+            uint32_t before = 0, total = 0;
+#pragma unroll
+            for (uint32_t w = 0; w < TILE_WAVES; ++w) {
+                const uint32_t c = lds_cnt[1u + w];
+                before += w < wib ? c : 0u;
+                total += c;
+            }
+            if (pass) lds_q[before + mbcnt(mask)] = e;
+            if (tid == 0) lds_cnt[0] = total;
+            __syncthreads();
+            T = __builtin_amdgcn_readfirstlane(lds_cnt[0]);
+            sum = 0.0f;
+            if (T == 0u || ns >= n_stages) break;
+            if (COUNT && tid == 0) atomicAdd(a.stage_entered + ns, (unsigned long long)T);
+        }
+        __syncthreads();   // lds_val / lds_tab / lds_cnt are rewritten by the next block
+        s = ns; b = nb; jb = njb; S = nS; first_node = nfirst; n_blocks = nnb; jn = njn;
+    }
+    return T;
+}
+
 template <bool TREES, bool COUNT>
 __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
     QEntry* lds_q = reinterpret_cast<QEntry*>(lds_dyn);                   // TILE_WAVES * TILE_WAVE_CAP entries
     uint32_t* lds_cnt = lds_dyn + TILE_WAVES * TILE_WAVE_CAP * 2;         // survivors per wave (re-packing)
-    uint32_t* lds_img = lds_dyn + TILE_LDS_HEADER / 4;                    // the image tile
+    uint32_t* lds_tab = lds_dyn + TILE_LDS_HEADER / 4;                    // stump-parallel: one stage's table, field-major
+    uint32_t* lds_img = lds_tab + a.tile_sp_pad;                          // the image tile (tile_sp_pad: dwords of lds_tab)
     const uint32_t lane = lane_id();
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     QEntry* q = lds_q + wib * TILE_WAVE_CAP;
@@ -583,13 +701,22 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
         const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
         // tile origin in the image: the first window's origin (same expression as below)
-        const uint32_t x0 = (uint32_t)__float2int_rn((float)ix0 * step);
-        const uint32_t y0 = (uint32_t)__float2int_rn((float)iy0 * step);
+        const uint32_t x0 = __builtin_amdgcn_readfirstlane((uint32_t)__float2int_rn((float)ix0 * step));
+        const uint32_t y0 = __builtin_amdgcn_readfirstlane((uint32_t)__float2int_rn((float)iy0 * step));
 
         __syncthreads();  // the previous tile's gathers are finished
+        // stage the tile: rows round-robin over the waves, 64 consecutive dwords per instruction,
+        // straight into LDS (buffer_load ... lds: no VGPR round trip, so every load of the tile is in
+        // flight at once instead of one load-wait-store per 256 bytes); the barrier drains them
         for (uint32_t rr = wib; rr < rows; rr += TILE_WAVES) {
             const uint32_t g_row = ((y0 + rr) * a.stride + x0) * 4u;   // uniform
-            for (uint32_t c = lane; c < pitch; c += 64u) lds_img[rr * pitch + c] = ld_u32(sum_f, c * 4u, g_row);
+            for (uint32_t c0 = 0; c0 < pitch; c0 += 64u) {
+                const uint32_t soff = __builtin_amdgcn_readfirstlane(g_row + c0 * 4u);   // keep it scalar
+                if (c0 + lane < pitch)
+                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                        sum_f, (__attribute__((address_space(3))) uint32_t*)(lds_img + rr * pitch + c0), 4,
+                        lane * 4u, soff, 0, 0);
+            }
         }
         __syncthreads();
 
@@ -671,6 +798,17 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                 const uint32_t first = min(wib * share, total);
                 q = lds_q + first;
                 n = min(share, total - first);
+                if (!TREES && st >= a.tile_sp_begin && total != 0u && total <= a.tile_sp_max) {
+                    // few windows left: finish the whole cascade stump-parallel; survivors are detections
+                    const uint32_t left = tile_stump_parallel<COUNT>(
+                        a, img, a.table + (size_t)scales[slot].tile_table_first * 16u, lds_q,
+                        reinterpret_cast<float*>(lds_q + TILE_SP_MAX_WINDOWS), lds_tab, lds_cnt, total, st, n_stages_total,
+                        lane, wib);
+                    q = lds_q;
+                    n = wib == 0u ? left : 0u;
+                    dest = a.n_pass;
+                    break;
+                }
                 if (at_boundary) {
                     if (total < max(a.tile_min_lanes, 1u) || st >= a.tile_end) {
                         dest = next_p;

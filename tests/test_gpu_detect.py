@@ -119,6 +119,8 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
             env.configure("tile_min_windows", minw)
             env.configure("tile_min_lanes", {3: 0, 10: 12, 22: 64, 14: 1, 7: 200}[tile_end])
             env.configure("tile_repack", {3: "", 10: "3,5", 22: "1,2,3,4,5,6,7,9,11,13,17", 14: "2", 7: "6"}[tile_end])
+            env.configure("tile_sp_begin", {3: 64, 10: 8, 22: 4, 14: 1, 7: 6}[tile_end])
+            env.configure("tile_sp_max", {3: 96, 10: 48, 22: 512, 14: 200, 7: 45}[tile_end])
             for split in ("", "22", "7", "2,4,6,9,12,15,18"):
                 env.configure("pass_split", split)
                 r = env.detect(c, frames, p)
@@ -127,11 +129,13 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
     finally:
         env.configure("pass_split", "")
         env.configure("blocks_per_cu", 8)
-        env.configure("tile_classes_kb", "36,64,140")
-        env.configure("tile_end", 8)
+        env.configure("tile_classes_kb", "-3,-2,-1")
+        env.configure("tile_end", 12)
         env.configure("tile_min_windows", 1024)
         env.configure("tile_min_lanes", 0)
-        env.configure("tile_repack", "3,5")
+        env.configure("tile_repack", ",".join(str(i) for i in range(2, 22)))
+        env.configure("tile_sp_begin", 4)
+        env.configure("tile_sp_max", 192)
 
 
 def test_scale_mask_partitions_the_result(env, cascades):

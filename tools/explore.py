@@ -31,7 +31,7 @@ if "tile" in what:
                     env.configure("tile_end", te); env.configure("pass_split", sp); env.configure("tile_min_lanes", ml)
                     r = run(default_params())
                     print(f"split={sp!r} tile_end={te} min_lanes={ml}: cascade {r.cascade_ms:.2f} ms passes {[round(x[2],2) for x in r.passes]}", flush=True)
-    env.configure("tile_classes_kb", "36,64,140"); env.configure("pass_split", ""); env.configure("tile_end", 8); env.configure("tile_min_lanes", 0)
+    env.configure("tile_classes_kb", "-3,-2,-1"); env.configure("pass_split", ""); env.configure("tile_end", 8); env.configure("tile_min_lanes", 0)
 if "ab" in what:
     env.configure("tile_min_lanes", 4096)   # tile waves always leave at the first boundary
     for k in (0, 4, 8, 10, 12, 14, 16, 20):
@@ -45,7 +45,7 @@ if "ab" in what:
                 ev = sum(rc.stage_entered[i] * int(c.stages["n_trees"][i]) for i in range(int(sp)))
                 out.append(f"{'tile' if classes != '0,0,0' else 'glob'} {r.passes[0][2]:.3f} ms {ev / r.passes[0][2] / 1e6:.1f} Gev/s")
             print(f"scale {k} s={scales[k].scale:.2f} stages[0,{sp}) windows={rc.windows}: " + " | ".join(out), flush=True)
-    env.configure("tile_classes_kb", "36,64,140"); env.configure("pass_split", ""); env.configure("tile_min_lanes", 0)
+    env.configure("tile_classes_kb", "-3,-2,-1"); env.configure("pass_split", ""); env.configure("tile_min_lanes", 0)
 if "repack" in what:
     for rp in ("", "3,5", "2,3,4,5,6,7", "3,5,6,7"):
         env.configure("tile_repack", rp)
@@ -68,6 +68,20 @@ if "b64" in what:
         r = run(default_params(), 2)
         print(f"split={sp!r} tile_end={te}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{l['ms']:.1f}" for l in r.launches), flush=True)
     env.configure("pass_split", ""); env.configure("tile_end", 8)
+if "sp" in what:
+    rp_all = ",".join(str(i) for i in range(2, 22))
+    for spb, spm, sp, te in ((64, 96, "5,8", 8), (6, 48, "5,8,12", 12), (6, 96, "5,8,12", 12), (6, 192, "5,8,12", 12), (5, 96, "5,8,12", 12), (5, 192, "5,8,12", 12),
+                             (4, 192, "5,8,12", 12), (4, 512, "5,8,12", 12), (3, 512, "5,8,12", 12), (5, 256, "5,9", 9), (5, 512, "5,8,12", 12)):
+        env.configure("tile_sp_begin", spb); env.configure("tile_sp_max", spm); env.configure("tile_repack", rp_all); env.configure("pass_split", sp); env.configure("tile_end", te)
+        r = run(default_params(), 2)
+        print(f"sp_begin={spb} sp_max={spm} split={sp!r} tile_end={te}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("tile_sp_begin", 4); env.configure("tile_sp_max", 192); env.configure("tile_repack", ",".join(str(i) for i in range(2, 22))); env.configure("pass_split", ""); env.configure("tile_end", 12)
+if "large" in what:
+    for acc, mdw in ((512, 600), (256, 600), (128, 600), (128, 1200), (64, 1200), (64, 2500), (32, 2500), (16, 5000)):
+        env.configure("tile_accept_windows", acc); env.configure("tile_max_dwords_per_window", mdw)
+        r = run(default_params(), 2)
+        print(f"accept={acc} max_dw/win={mdw}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("tile_accept_windows", 256); env.configure("tile_max_dwords_per_window", 600)
 if "accept" in what:
     for classes in ("36,64,140", "36,64,100", "36,72,0", "40,80,0", "52,80,0", "52,80,140"):
         env.configure("tile_classes_kb", classes)
@@ -75,7 +89,7 @@ if "accept" in what:
             env.configure("tile_min_windows", minw); env.configure("tile_accept_windows", acc)
             r = run(default_params())
             print(f"classes={classes} minw={minw} accept={acc}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
-    env.configure("tile_classes_kb", "36,64,140"); env.configure("tile_min_windows", 1024); env.configure("tile_accept_windows", 512)
+    env.configure("tile_classes_kb", "-3,-2,-1"); env.configure("tile_min_windows", 1024); env.configure("tile_accept_windows", 256)
 if "minw" in what:
     for minw in (256, 512, 1024, 2048):
         env.configure("tile_min_windows", minw)
