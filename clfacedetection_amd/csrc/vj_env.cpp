@@ -95,6 +95,8 @@ struct vj_env {
     int n_cu = 0;
     // image buffers
     DevBuf d_gray, d_sum, d_sqsum, d_band_sum, d_band_sq, d_band_sqp;
+    int slack_w = 0, slack_h = 0, slack_frames = 0;   // layout whose slack rows are known to be zero
+    void *slack_sum = nullptr, *slack_sq = nullptr;
     // survivor queues + counters + detections
     DevBuf d_q[MAX_PASSES], d_counts, d_det;   // d_q[p]: windows waiting to enter pass p (p >= 1)
     uint32_t det_cap = 0;
@@ -104,9 +106,9 @@ struct vj_env {
     std::map<PlanKey, std::unique_ptr<Plan>> plans;
     // tunables (env vars, read once)
     int blocks_per_cu = 8;
-    int tile_class_kb[TILE_CLASSES] = {-3, -2, -1};  // image-tile LDS budget per class in KiB; -k = what lets k
+    int tile_class_kb[TILE_CLASSES] = {-2, -1, 0};  // image-tile LDS budget per class in KiB; -k = what lets k
                                                      // workgroups share a CU's 160 KiB; all 0 disables the tile path
-    int tile_min_windows = 1024;  // a class is acceptable for a scale when a tile holds at least this many windows
+    int tile_min_windows = 768;   // a class is acceptable for a scale when a tile holds at least this many windows
     int tile_max_dwords_per_window = 600;  // staging a tile must stay far cheaper than gathering its windows from L2
     int tile_accept_windows = 256;  // scales whose best tile holds fewer windows stay on the global-gather path
     int tile_end = 12;            // tile launches never enter a pass that begins at or beyond this stage
@@ -455,12 +457,22 @@ static int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes
     ia.sqsum = (uint64_t*)e->d_sqsum.p;
     ia.frame_elems = frame_elems_for(W, H);
     // the slack rows after row H (and the alignment tail) must read as zero
+    // (the kernels never write there, so once per buffer layout is enough)
     const size_t used = (size_t)(W + 1) * (size_t)(H + 1);
-    for (int f = 0; f < frames; ++f) {
+    const bool zeroed = e->slack_w == W && e->slack_h == H && e->slack_frames >= frames && e->slack_sum == e->d_sum.p &&
+                        e->slack_sq == e->d_sqsum.p;
+    for (int f = 0; f < frames && !zeroed; ++f) {
         HIP_TRY(hipMemsetAsync((uint32_t*)e->d_sum.p + (size_t)f * ia.frame_elems + used, 0,
                                (ia.frame_elems - used) * 4, e->stream));
         HIP_TRY(hipMemsetAsync((uint64_t*)e->d_sqsum.p + (size_t)f * ia.frame_elems + used, 0,
                                (ia.frame_elems - used) * 8, e->stream));
+    }
+    if (!zeroed) {
+        e->slack_w = W;
+        e->slack_h = H;
+        e->slack_frames = frames;
+        e->slack_sum = e->d_sum.p;
+        e->slack_sq = e->d_sqsum.p;
     }
     int hrc = launch_integral(ia, e->stream);
     if (hrc) {

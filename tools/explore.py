@@ -31,7 +31,7 @@ if "tile" in what:
                     env.configure("tile_end", te); env.configure("pass_split", sp); env.configure("tile_min_lanes", ml)
                     r = run(default_params())
                     print(f"split={sp!r} tile_end={te} min_lanes={ml}: cascade {r.cascade_ms:.2f} ms passes {[round(x[2],2) for x in r.passes]}", flush=True)
-    env.configure("tile_classes_kb", "-3,-2,-1"); env.configure("pass_split", ""); env.configure("tile_end", 8); env.configure("tile_min_lanes", 0)
+    env.configure("tile_classes_kb", "-2,-1,0"); env.configure("pass_split", ""); env.configure("tile_end", 8); env.configure("tile_min_lanes", 0)
 if "ab" in what:
     env.configure("tile_min_lanes", 4096)   # tile waves always leave at the first boundary
     for k in (0, 4, 8, 10, 12, 14, 16, 20):
@@ -45,7 +45,7 @@ if "ab" in what:
                 ev = sum(rc.stage_entered[i] * int(c.stages["n_trees"][i]) for i in range(int(sp)))
                 out.append(f"{'tile' if classes != '0,0,0' else 'glob'} {r.passes[0][2]:.3f} ms {ev / r.passes[0][2] / 1e6:.1f} Gev/s")
             print(f"scale {k} s={scales[k].scale:.2f} stages[0,{sp}) windows={rc.windows}: " + " | ".join(out), flush=True)
-    env.configure("tile_classes_kb", "-3,-2,-1"); env.configure("pass_split", ""); env.configure("tile_min_lanes", 0)
+    env.configure("tile_classes_kb", "-2,-1,0"); env.configure("pass_split", ""); env.configure("tile_min_lanes", 0)
 if "repack" in what:
     for rp in ("", "3,5", "2,3,4,5,6,7", "3,5,6,7"):
         env.configure("tile_repack", rp)
@@ -82,6 +82,14 @@ if "large" in what:
         r = run(default_params(), 2)
         print(f"accept={acc} max_dw/win={mdw}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
     env.configure("tile_accept_windows", 256); env.configure("tile_max_dwords_per_window", 600)
+if "minw2" in what:
+    for classes in ("-3,-2,-1", "-4,-2,-1", "-3,-2,0", "-4,-3,-2", "-2,-1,0"):
+        env.configure("tile_classes_kb", classes)
+        for minw, acc in ((1024, 256), (512, 256), (256, 256), (768, 256), (2048, 256), (512, 128)):
+            env.configure("tile_min_windows", minw); env.configure("tile_accept_windows", acc)
+            r = run(default_params(), 2)
+            print(f"classes={classes} minw={minw} accept={acc}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("tile_classes_kb", "-2,-1,0"); env.configure("tile_min_windows", 768); env.configure("tile_accept_windows", 256)
 if "accept" in what:
     for classes in ("36,64,140", "36,64,100", "36,72,0", "40,80,0", "52,80,0", "52,80,140"):
         env.configure("tile_classes_kb", classes)
@@ -89,13 +97,13 @@ if "accept" in what:
             env.configure("tile_min_windows", minw); env.configure("tile_accept_windows", acc)
             r = run(default_params())
             print(f"classes={classes} minw={minw} accept={acc}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
-    env.configure("tile_classes_kb", "-3,-2,-1"); env.configure("tile_min_windows", 1024); env.configure("tile_accept_windows", 256)
+    env.configure("tile_classes_kb", "-2,-1,0"); env.configure("tile_min_windows", 768); env.configure("tile_accept_windows", 256)
 if "minw" in what:
     for minw in (256, 512, 1024, 2048):
         env.configure("tile_min_windows", minw)
         r = run(default_params())
         print(f"minw={minw}: cascade {r.cascade_ms:.2f} ms passes {[round(x[2],2) for x in r.passes]}", flush=True)
-    env.configure("tile_min_windows", 1024)
+    env.configure("tile_min_windows", 768)
 if "occ" in what:
     for b in (1, 2, 4, 8, 10):
         env.configure("blocks_per_cu", b)
