@@ -223,6 +223,55 @@ def test_grouping_of_dense_detections(env, oracle, cascades):
     assert got["weight"].astype(int).tolist() == w.tolist() and len(got) > 0
 
 
+def test_config4_4096_alt_tree(env, oracle, cascades):
+    """BASELINE config 4: one 4096x4096 frame, frontalface_alt_tree (stage tree, 8468 stumps, 56 scales,
+    53,305,712 windows).  Full-size checks by size-independent properties + exact parity on the largest
+    scales (selected through min_window_size, which both sides implement)."""
+    c, a = cascades("frontalface_alt_tree")
+    img = synth.frame("noise", 4096, 4096, 4096)
+    p = default_params(flags=VJ_FLAG_COUNTERS)
+    r1 = env.detect(c, img, p)
+    assert r1.windows == 53305712 == r1.stage_entered[0]
+    r2 = env.detect(c, img, default_params())
+    assert np.array_equal(r1.rects, r2.rects)                                   # repeatable, counters on/off
+    n = len(c.plan_scales(4096, 4096))
+    assert n == 56
+    parts = [env.detect(c, img, default_params(scales=range(k, n, 2))).rects for k in range(2)]
+    merged = np.concatenate(parts)
+    merged = merged[np.lexsort((merged["x"], merged["y"], merged["scale_idx"], merged["frame"]))]
+    assert np.array_equal(merged, r1.rects)                                     # scales are independent
+    # exact parity on the scales with windows >= 900 px (few windows: the oracle is quick there)
+    big = env.detect(c, img, default_params(flags=VJ_FLAG_COUNTERS, min_w=900, min_h=900))
+    ro, st = oracle.detect(a, img, min_size=(900, 900))
+    assert as_list(big.rects) == as_list(ro) and big.stage_entered == st["stage_entered"]
+    assert as_list(r1.rects[r1.rects["w"] >= 900]) == as_list(ro)
+
+
+def test_config5_two_cascades_on_rois(env, oracle, cascades):
+    """BASELINE config 5 shape: frontalface_alt2 on 1280x720 frames, then haarcascade_eye on every face
+    ROI (ROI = sub-image view: pointer + stride).  Both legs against the oracle."""
+    from clfacedetection_amd import group_rectangles
+    c2, a2 = cascades("frontalface_alt2")
+    ce, ae = cascades("eye")
+    frames = synth.batch(4, 720, 1280, seed0=777, kinds=("noise", "blocks"))
+    faces = env.detect(c2, frames, default_params(flags=VJ_FLAG_COUNTERS))
+    n_rois = 0
+    for f in range(len(frames)):
+        ro, st = oracle.detect(a2, frames[f])
+        mine = faces.rects[faces.rects["frame"] == f]
+        assert as_list(mine) == as_list(ro)
+        for face in mine[:6]:
+            x, y, w, h = (int(face[k]) for k in ("x", "y", "w", "h"))
+            roi = frames[f][y:y + h, x:x + w]                  # strided view, not a copy
+            if roi.shape[0] < 30 or roi.shape[1] < 30:
+                continue
+            eyes = env.detect(ce, roi, default_params(flags=VJ_FLAG_COUNTERS))
+            eo, est = oracle.detect(ae, np.ascontiguousarray(roi))
+            assert as_list(eyes.rects) == as_list(eo) and eyes.stage_entered == est["stage_entered"]
+            n_rois += 1
+    assert len(faces.rects) > 0 and n_rois > 0
+
+
 def test_native_library_is_the_one_running(env):
     """The GPU tests must run hand-written HIP: libvjhip.so is mapped into this process."""
     maps = open("/proc/self/maps").read()
