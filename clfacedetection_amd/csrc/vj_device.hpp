@@ -32,7 +32,11 @@ struct ScaleDev {
     uint32_t tile_th;      // window rows per tile (tile_tw * tile_th <= TILE_WAVES * TILE_WAVE_CAP)
     uint32_t reserved0;
     uint32_t tile_class;   // LDS size class of the tile launch
-    uint32_t pad[9];
+    uint32_t tile_half;    // != 0: step is exactly 2 and the tile rows are de-interleaved: even image columns
+                           // first, odd columns from element tile_half on (window origins are all even, so a
+                           // wave's gathers of one corner touch CONSECUTIVE dwords: no bank conflicts)
+    int32_t  te_dw;        // equ_rect left->right distance in tile elements (signed when de-interleaved)
+    uint32_t pad[7];
 };
 static_assert(sizeof(ScaleDev) == 128, "ScaleDev is 128 bytes");
 
@@ -45,7 +49,7 @@ struct StageDev {
     int32_t  on_fail;      // next stage, or -2 reject
     uint32_t n_trees;
     uint32_t order;        // stage-tree sweep: the i-th record holds the i-th stage to visit (topological)
-    uint32_t pad;
+    uint32_t sp_first;     // stump-parallel finish: index of the stage's first block in CascadeArgs::sp_blocks
 };
 static_assert(sizeof(StageDev) == 32, "StageDev is 32 bytes");
 
@@ -72,17 +76,23 @@ struct DetEntry {
     uint32_t scale;        // index into ScaleDev[]
 };
 
+// One block of <= 64 consecutive nodes of a stage (stump-parallel finish of the tile kernel).
+struct SpBlock {
+    uint32_t first_node;   // flat node index
+    uint32_t desc;         // jn | jb << 8 | b << 16 | nb << 20 | stage << 24
+};
+
 constexpr int UNIT_WINDOWS = 512;   // windows per wave-unit == per-wave LDS queue capacity
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MAX_SCALES = 128;
 constexpr int MAX_PASSES = 8;         // == VJ_MAX_PASSES
-constexpr int TILE_WAVES = 8;        // waves per workgroup of the LDS-tile kernel
+constexpr int TILE_WAVES = 8;        // waves per workgroup of the LDS-tile kernel (16 measured slower)
 constexpr int TILE_W = 64;           // windows per tile row (= lanes of a wave)
 constexpr int TILE_WAVE_CAP = 256;    // windows (= LDS queue entries) per wave of the tile kernel
 constexpr int TILE_CLASSES = 3;       // LDS size classes, one launch each
-constexpr int TILE_LDS_HEADER = (TILE_WAVES * TILE_WAVE_CAP * 2 + 16) * 4;  // queues + per-wave counts, bytes
-constexpr int TILE_SP_MAX_WINDOWS = 512;  // windows a tile may carry into the stump-parallel finish (one per thread)
-constexpr int TILE_SP_GROUP = 44;         // windows whose stump values fit the value buffer at a time
+constexpr int TILE_LDS_HEADER = (TILE_WAVES * TILE_WAVE_CAP * 2 + 32) * 4;  // queues + per-wave counts, bytes
+constexpr int TILE_SP_MAX_WINDOWS = 384;  // windows a tile may carry into the stump-parallel finish (one per thread)
+constexpr int TILE_SP_MAX_BLOCKS = 4;     // blocks of 64 stumps per stage at most (stages of <= 256 nodes)
 constexpr int TILE_SP_BLOCK = 64;         // stumps evaluated per round and window (= lanes of a wave)
 constexpr int TILE_SP_FIELDS = 14;        // dwords of a node record kept in the LDS copy of a stage's table
 
@@ -122,8 +132,10 @@ struct CascadeArgs {
     // re-pack point at or after tile_sp_begin, its 512 lanes evaluate (window, stump) pairs in parallel
     // and one lane per window adds the stump values in cascade order — through the last stage.
     uint32_t  tile_sp_begin;                // >= number of stages: disabled
-    uint32_t  tile_sp_pad;                  // dwords of LDS reserved for one block of node records (0 = off)
-    uint32_t  tile_sp_max;                  // enter the finish when at most this many windows are left (<= 512)
+    uint32_t  tile_sp_pad;                  // dwords of LDS reserved for the finish: two record blocks + leaf values (0 = off)
+    uint32_t  tile_sp_max;                  // enter the finish when at most this many windows are left
+    const SpBlock* sp_blocks;               // per block of <= 64 stumps, all stages in order
+    uint32_t  n_sp_blocks;
     DetEntry* det;              // detections (last pass)
     uint32_t* det_count;
     uint32_t  det_cap;

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <map>
@@ -74,7 +75,8 @@ struct Plan {
     uint32_t n_order = 0;  // stages reachable from stage 0, in StageDev::order
     StageProgram prog;
     // device copies
-    DevBuf d_table, d_scales, d_stages, d_units, d_tile_units;
+    DevBuf d_table, d_scales, d_stages, d_units, d_tile_units, d_sp_blocks;
+    uint32_t n_sp_blocks = 0;
     int frames_q = 0;  // frames the ScaleDev.q_base/q_cap currently describe
 };
 
@@ -115,7 +117,8 @@ struct vj_env {
     int tile_min_lanes = 0;       // a tile leaves at a pass boundary when fewer windows than this survive in it
     unsigned long long tile_repack_mask = 0x3ffffcull;  // stages (2..21) before which a tile re-packs its survivors
     int tile_sp_begin = 4;        // first stage at which a tile may switch to the stump-parallel finish (>= 64: never)
-    int tile_sp_max = 192;        // ... once at most this many of its windows survive
+    int tile_sp_max = 192;
+    int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales        // ... once at most this many of its windows survive
     std::vector<int> split_override;
 };
 
@@ -217,9 +220,14 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     const uint32_t stride = (uint32_t)W + 1u;
     const size_t n_nodes = c.nodes.size();
 
-    // stump-parallel finish: LDS room for one block of node records, field-major (dwords)
-    if (!pl->trees && !pl->general && e->tile_sp_begin < (int)c.stages.size())
-        pl->sp_pad = ((uint32_t)TILE_SP_FIELDS * (TILE_SP_BLOCK + 1u) + 3u) & ~3u;
+    // stump-parallel finish: LDS room for two blocks of node records (field-major) and the leaf values of
+    // the largest stage (dwords); stages of more than TILE_SP_MAX_BLOCKS * 64 nodes rule it out
+    if (!pl->trees && !pl->general && e->tile_sp_begin < (int)c.stages.size()) {
+        uint32_t mx = 0;
+        for (size_t s = 0; s < c.stages.size(); ++s) mx = std::max(mx, pl->prog.n_nodes[s]);
+        if (mx <= (uint32_t)TILE_SP_MAX_BLOCKS * TILE_SP_BLOCK)
+            pl->sp_pad = (2u * TILE_SP_FIELDS * (TILE_SP_BLOCK + 1u) + 2u * mx + 3u) & ~3u;
+    }
     const uint32_t tile_header_bytes = TILE_LDS_HEADER + pl->sp_pad * 4u;
     std::vector<NodeRec> table;
     for (const vj_scale_info& si : pl->scales_all) {
@@ -307,9 +315,13 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         if (sd.tile_rw) {
             sd.tile_table_first = (uint32_t)table.size();
             table.resize(table.size() + n_nodes);
-            rc = build_node_table_stride(c, sd.tile_pitch, si, table.data() + sd.tile_table_first);
+            // step exactly 2: every window origin is an even column -> de-interleave the tile rows
+            sd.tile_half = (e->tile_deinterleave && si.step == 2.0f) ? (sd.tile_pitch + 1u) / 2u : 0u;
+            rc = build_node_table_stride(c, sd.tile_pitch, si, table.data() + sd.tile_table_first, sd.tile_half);
             if (rc) return rc;
-            sd.te_lt = (uint32_t)si.equ_y * sd.tile_pitch + (uint32_t)si.equ_x;
+            auto col = [&](uint32_t cx) { return sd.tile_half ? (cx & 1u) * sd.tile_half + (cx >> 1) : cx; };
+            sd.te_lt = (uint32_t)si.equ_y * sd.tile_pitch + col((uint32_t)si.equ_x);
+            sd.te_dw = (int32_t)col((uint32_t)(si.equ_x + si.equ_w)) - (int32_t)col((uint32_t)si.equ_x);
             sd.te_dh = (uint32_t)si.equ_h * sd.tile_pitch;
             sd.tiles_x = (sd.nx + sd.tile_tw - 1) / sd.tile_tw;
         } else {
@@ -337,6 +349,19 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         pl->stages.push_back(sd);
     }
     pl->n_order = (uint32_t)order.size();
+    // blocks of <= 64 consecutive nodes per stage, balanced, for the stump-parallel finish of the tile kernel
+    std::vector<SpBlock> sp_blocks;
+    for (size_t s = 0; s < c.stages.size(); ++s) {
+        const uint32_t S = pl->prog.n_nodes[s], nb = (S + TILE_SP_BLOCK - 1u) / TILE_SP_BLOCK;
+        pl->stages[s].sp_first = (uint32_t)sp_blocks.size();
+        uint32_t jb = 0;
+        for (uint32_t b = 0; b < nb && nb <= (uint32_t)TILE_SP_MAX_BLOCKS && s < 256; ++b) {
+            const uint32_t jn = S / nb + (b < S % nb ? 1u : 0u);
+            sp_blocks.push_back(SpBlock{pl->prog.first_node[s] + jb, jn | (jb << 8) | (b << 16) | (nb << 20) | ((uint32_t)s << 24)});
+            jb += jn;
+        }
+    }
+    pl->n_sp_blocks = (uint32_t)sp_blocks.size();
     pl->pass_bounds = default_pass_bounds(c, pl->prog, e->split_override);
     if (pl->general) pl->pass_bounds = {0u, pl->n_order};  // one pass over StageDev::order (run_stages_general)
     // tile launches run deeper than the global-gather first pass (LDS gathers are ~10x cheaper)
@@ -362,6 +387,9 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     if ((rc = pl->d_stages.ensure(pl->stages.size() * sizeof(StageDev)))) return rc;
     if ((rc = pl->d_units.ensure(std::max<size_t>(pl->units.size(), 1) * sizeof(UnitDev)))) return rc;
     if ((rc = pl->d_tile_units.ensure(std::max<size_t>(pl->tile_units.size(), 1) * sizeof(UnitDev)))) return rc;
+    if ((rc = pl->d_sp_blocks.ensure(std::max<size_t>(sp_blocks.size(), 1) * sizeof(SpBlock)))) return rc;
+    if (!sp_blocks.empty())
+        HIP_TRY(hipMemcpy(pl->d_sp_blocks.p, sp_blocks.data(), sp_blocks.size() * sizeof(SpBlock), hipMemcpyHostToDevice));
     if (!pl->tile_units.empty())
         HIP_TRY(hipMemcpy(pl->d_tile_units.p, pl->tile_units.data(), pl->tile_units.size() * sizeof(UnitDev),
                           hipMemcpyHostToDevice));
@@ -410,6 +438,7 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
         pl->d_stages.release();
         pl->d_units.release();
         pl->d_tile_units.release();
+        pl->d_sp_blocks.release();
         return rc;
     }
     *out = pl.get();
@@ -591,6 +620,8 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.tile_repack_mask = e->tile_repack_mask;
         ca.tile_sp_begin = pl->sp_pad ? (uint32_t)e->tile_sp_begin : 0xffffffffu;
         ca.tile_sp_pad = pl->sp_pad;
+        ca.sp_blocks = (const SpBlock*)pl->d_sp_blocks.p;
+        ca.n_sp_blocks = pl->n_sp_blocks;
         ca.tile_sp_max = (uint32_t)std::min(e->tile_sp_max, (int)TILE_SP_MAX_WINDOWS);
         int launches = 0;
         std::vector<vj_launch> linfo;
@@ -657,7 +688,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 ta.n_tile_units = n_cls;
                 ta.tile_lds_bytes = pl->class_lds[cls];
                 // workgroups per CU: what the LDS allows (160 KiB per CU), at most 4 x 8 waves
-                const int per_cu = std::max(1, std::min(4, (int)(160u * 1024u / ta.tile_lds_bytes)));
+                const int per_cu = std::max(1, std::min(32 / TILE_WAVES, (int)(160u * 1024u / ta.tile_lds_bytes)));
                 const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
                 const uint32_t deepest = std::min<uint32_t>((uint32_t)pl->stages.size(), handover);
                 if ((rc = begin_launch(VJ_LAUNCH_TILE, (int)cls, 0, deepest, ta.tile_lds_bytes, e->stream))) return rc;
@@ -737,6 +768,13 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 tm->launch[i].ms = prev + ms;
             }
             tm->n_launches = (int32_t)linfo.size();
+        }
+        if (getenv("VJ_DEBUG_STAMPS")) {  // diagnostic build (-DVJ_STAMPS=1): phase cycle sums of the tile kernel
+            const unsigned long long* se =
+                (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * MAX_SCALES + 2);
+            fprintf(stderr, "vj stamps:");
+            for (int i = 40; i < 60; ++i) fprintf(stderr, " %llu", se[i]);
+            fprintf(stderr, "\n");
         }
         if (count) {
             const unsigned long long* se =
@@ -848,6 +886,7 @@ static void drop_plans(vj_env* e) {
         kv.second->d_stages.release();
         kv.second->d_units.release();
         kv.second->d_tile_units.release();
+        kv.second->d_sp_blocks.release();
     }
     e->plans.clear();
 }
@@ -891,6 +930,12 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "tile_sp_max") == 0) {
         e->tile_sp_max = std::max(0, std::min(atoi(value), (int)TILE_SP_MAX_WINDOWS));
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_deinterleave") == 0) {
+        e->tile_deinterleave = atoi(value) != 0;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
         return VJ_OK;
     }
     if (strcmp(key, "tile_sp_begin") == 0) {

@@ -56,6 +56,7 @@ enum { NODE_LEFT_IS_NODE = 1, NODE_RIGHT_IS_NODE = 2, NODE_TREE_LAST = 4 };
 
 // Fill recs[n_nodes] for one scale (precomputeKernelCascade, clod.cpp:529-578).
 int build_node_table(const vj_cascade& c, int width, const vj_scale_info& s, NodeRec* recs);
-int build_node_table_stride(const vj_cascade& c, uint32_t stride, const vj_scale_info& s, NodeRec* recs);
+int build_node_table_stride(const vj_cascade& c, uint32_t stride, const vj_scale_info& s, NodeRec* recs,
+                            uint32_t deint_half);
 
 }  // namespace vj

@@ -15,6 +15,9 @@
 #include <hip/hip_runtime.h>
 #include "vj_device.hpp"
 
+#ifndef VJ_STAMPS
+#define VJ_STAMPS 0
+#endif
 namespace vj {
 
 // Read-only, wave-uniform data goes through address space 4 so that the compiler may
@@ -49,6 +52,11 @@ __device__ __forceinline__ uint64_t ld_u64(rsrc_t r, uint32_t lane_off, uint32_t
     const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, uniform_off, 0);
     return (uint64_t)v[0] | ((uint64_t)v[1] << 32);
 }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
+// global load (s_waitcnt vmcnt(0)), which would serialise the record prefetches of the stump-parallel
+// finish behind a full memory round trip per block.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // 64-byte node record as the scalar unit loads it (one s_load_dwordx16).
 typedef uint32_t NodeRecDev __attribute__((ext_vector_type(16)));
@@ -269,7 +277,9 @@ template <typename Img>
 __device__ __forceinline__ float node_rect_sum(const Img& img, const NodeRecDev& r, uint32_t off) {
     const uint32_t lt0 = r[0], lt1 = r[1], lt2 = r[2];
     const uint32_t dh0 = r[3], dh1 = r[4], dh2 = r[5];
-    const uint32_t dw0 = r[6] & 0xffffu, dw1 = r[6] >> 16, dw2 = r[7] & 0xffffu;
+    // left->right distances are signed 16-bit (negative only in de-interleaved LDS tiles)
+    const uint32_t dw0 = (uint32_t)(int32_t)(int16_t)(r[6] & 0xffffu), dw1 = (uint32_t)((int32_t)r[6] >> 16),
+                   dw2 = (uint32_t)(int32_t)(int16_t)(r[7] & 0xffffu);
     const float w0 = __uint_as_float(r[8]), w1 = __uint_as_float(r[9]), w2 = __uint_as_float(r[10]);
     // u32 wrap-around on the four corners, one cast, one multiply per rectangle
     const uint32_t r0 = img.ld(off, lt0) - img.ld(off, lt0 + dw0) - img.ld(off, lt0 + dh0) + img.ld(off, lt0 + dh0 + dw0);
@@ -558,119 +568,158 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
 // as the global-gather pass, as {global byte offset, variance}.
 
 // Stump-parallel finish of a tile (stump cascades).  lds_q[0..T) holds the tile's T <= TILE_SP_MAX_WINDOWS
-// surviving windows.  Per stage: the stage's node records are copied to LDS field-major; wave w of each
-// round takes one window and its 64 lanes take 64 consecutive stumps — every (window, stump) value
-// alpha[rect_sum >= thr * var] is independent — and store the values; then lane t of wave 0 adds window
-// t's values IN STUMP ORDER (stage_sum += alpha, clod.cl:81), exactly the sequence a single lane would
-// have produced, compares with the stage threshold and wave 0 compacts the survivors.  Replaces the
-// serial tail (one thin wave, ~300 cycles per stump) of the late stages.
+// surviving windows.  Per stage, in blocks of <= 64 consecutive stumps: the block's node records are copied
+// to LDS field-major (the next block is prefetched into registers meanwhile); lane j owns stump j of the
+// block, wave w takes windows w, w + 8, ...; a (window, block) result is 64 bits — which stumps answered
+// alpha[1] — so one __ballot per window is all that is stored.  After the stage's last block, thread t walks
+// window t's bits IN STUMP ORDER and adds the leaf values (stage_sum += alpha[rect_sum >= norm_threshold],
+// clod.cl:81) — exactly the sequence of f32 additions a single lane would have made — compares with the
+// stage threshold, and the survivors are compacted across the waves.  Replaces the serial tail (one thin
+// wave, ~300 cycles per stump) of the late stages.
 template <bool COUNT>
 __device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, const LdsImg& img,
                                                         const uint32_t* table /* the scale's tile table, global */,
-                                                        QEntry* lds_q, float* lds_val, uint32_t* lds_tab,
+                                                        QEntry* lds_q, unsigned long long* lds_mask, uint32_t* lds_sp,
                                                         uint32_t* lds_cnt, uint32_t T, uint32_t st_begin,
-                                                        uint32_t n_stages, uint32_t lane, uint32_t wib) {
+                                                        uint32_t n_stages, uint32_t lane, uint32_t wib,
+                                                        unsigned long long& t_last) {
+    unsigned long long sp_acc[5] = {0, 0, 0, 0, 0};
+#define SPSTAMP(ph) do { if (VJ_STAMPS && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sp_acc[ph] += t_ - t_last; t_last = t_; } } while (0)
+#define SPFLUSH() do { if (VJ_STAMPS && threadIdx.x == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(a.stage_entered + 54 + i_, sp_acc[i_]); } } while (0)
     kptr<StageDev> stages = as_k(a.stages);
+    kptr<uint32_t> blocks = as_k(reinterpret_cast<const uint32_t*>(a.sp_blocks));   // {first_node, desc} pairs
     const uint32_t tid = wib * 64u + lane;
-    constexpr uint32_t PITCH = TILE_SP_BLOCK + 1u;   // odd pitch: column reads/writes hit distinct banks
+    constexpr uint32_t PITCH = TILE_SP_BLOCK + 1u;   // odd pitch: the field-major copy is written conflict-free
+    constexpr uint32_t TABSZ = TILE_SP_FIELDS * PITCH;
     constexpr uint32_t NT = TILE_WAVES * 64u;
-    // Blocks of <= 64 consecutive stumps, balanced inside each stage.  The records of block k+1 are
-    // fetched from global memory into registers (2 dwords per thread) while block k is evaluated.
-    uint32_t s = st_begin;
-    uint32_t S = stages[s].n_nodes, first_node = stages[s].first_node;
-    uint32_t n_blocks = (S + TILE_SP_BLOCK - 1u) / TILE_SP_BLOCK, b = 0, jb = 0;
-    uint32_t jn = S / n_blocks + (0u < S % n_blocks ? 1u : 0u);
-    uint32_t pre0 = 0, pre1 = 0;
-    {
-        const uint32_t* src = table + (size_t)(first_node + jb) * 16u;
-        if (tid < jn * 16u) pre0 = src[tid];
-        if (tid + NT < jn * 16u) pre1 = src[tid + NT];
+    constexpr uint32_t MAXB = TILE_SP_MAX_BLOCKS;
+    constexpr int DEPTH = 4;                                         // record blocks in flight from global memory
+    uint32_t* lds_tab = lds_sp;                                      // two buffers of TABSZ dwords
+    uint32_t* lds_lx = lds_sp + 2u * TABSZ;   // {left, right} bit patterns of every stump of the stage
+    const uint32_t g_end = a.n_sp_blocks;
+    uint32_t g = stages[st_begin].sp_first;   // running block number over all stages
+    // records of block x: 16 dwords per node, thread t fetches dwords t and t + 512 of the block
+    uint32_t pre0[DEPTH], pre1[DEPTH];
+#pragma unroll
+    for (int u = 0; u < DEPTH; ++u) {
+        pre0[u] = 0u;
+        pre1[u] = 0u;
+        if (g + (uint32_t)u < g_end) {
+            const uint32_t jn = blocks[2u * (g + (uint32_t)u) + 1u] & 0xffu;
+            const uint32_t* src = table + (size_t)blocks[2u * (g + (uint32_t)u)] * 16u;
+            if (tid < jn * 16u) pre0[u] = src[tid];
+            if (tid + NT < jn * 16u) pre1[u] = src[tid + NT];
+        }
     }
-    float sum = 0.0f;   // thread t < T owns window t
-    if (COUNT && tid == 0) atomicAdd(a.stage_entered + s, (unsigned long long)T);
+    if (COUNT && tid == 0) atomicAdd(a.stage_entered + st_begin, (unsigned long long)T);
     while (true) {
-        // 1. this block's node records -> LDS, field-major: lane j reads field f at lds_tab[f * PITCH + j]
-        if (tid < jn * 16u && (tid & 15u) < (uint32_t)TILE_SP_FIELDS) lds_tab[(tid & 15u) * PITCH + (tid >> 4)] = pre0;
-        if (tid + NT < jn * 16u && (tid & 15u) < (uint32_t)TILE_SP_FIELDS)
-            lds_tab[(tid & 15u) * PITCH + ((tid + NT) >> 4)] = pre1;
-        __syncthreads();
-        // next block (possibly of the next stage — harmless if this stage turns out to be the last)
-        uint32_t ns = s, nb = b + 1u, njb = jb + jn, nS = S, nfirst = first_node, nnb = n_blocks;
-        if (nb == n_blocks) {
-            ns = s + 1u;
-            nb = 0u;
-            njb = 0u;
-            if (ns < n_stages) {
-                nS = stages[ns].n_nodes;
-                nfirst = stages[ns].first_node;
-                nnb = (nS + TILE_SP_BLOCK - 1u) / TILE_SP_BLOCK;
-            }
-        }
-        const uint32_t njn = nS / nnb + (nb < nS % nnb ? 1u : 0u);
-        if (ns < n_stages) {
-            const uint32_t* src = table + (size_t)(nfirst + njb) * 16u;
-            if (tid < njn * 16u) pre0 = src[tid];
-            if (tid + NT < njn * 16u) pre1 = src[tid + NT];
-        }
-        // 2./3. groups of TILE_SP_GROUP windows share the value buffer: wave w handles windows
-        // gb + w, gb + w + 8, ... (lane j = stump jb + j), then thread t < T adds window t's values
-        // in stump order (stage_sum += alpha); loads issued 8 at a time
-        for (uint32_t gb = 0; gb < T; gb += TILE_SP_GROUP) {
-            const uint32_t gcount = min((uint32_t)TILE_SP_GROUP, T - gb);
-            for (uint32_t w = wib; w < gcount; w += TILE_WAVES) {
-                if (lane < jn) {
-                    const QEntry e = lds_q[gb + w];   // broadcast
-                    NodeRecDev r;
 #pragma unroll
-                    for (int f = 0; f < TILE_SP_FIELDS; ++f) r[f] = lds_tab[f * PITCH + lane];
-                    r[14] = 0u;
-                    r[15] = 0u;
-                    const float norm_threshold = __uint_as_float(r[11]) * e.var;
-                    const float rect_sum = node_rect_sum(img, r, e.off);
-                    lds_val[w * PITCH + lane] = (rect_sum >= norm_threshold) ? __uint_as_float(r[13]) : __uint_as_float(r[12]);
+        for (int u = 0; u < DEPTH; ++u) {
+            const uint32_t desc = blocks[2u * g + 1u];
+            const uint32_t jn = desc & 0xffu, jb = (desc >> 8) & 0xffu, b = (desc >> 16) & 0xfu, nb = (desc >> 20) & 0xfu;
+            const uint32_t s = desc >> 24;
+            uint32_t* tab = lds_tab + (g & 1u) * TABSZ;
+            // 1. this block's records -> LDS field-major (lane j reads field f at tab[f * PITCH + j]); the leaf
+            // values also go to lds_lr in stage order for the accumulation
+            {
+                const uint32_t i0 = tid, i1 = tid + NT;
+                if (i0 < jn * 16u) {
+                    const uint32_t f = i0 & 15u, j = i0 >> 4;
+                    if (f < (uint32_t)TILE_SP_FIELDS) tab[f * PITCH + j] = pre0[u];
+                    if (f == 12u) lds_lx[(jb + j) * 2u] = pre0[u];
+                    if (f == 13u) lds_lx[(jb + j) * 2u + 1u] = pre0[u];
+                }
+                if (i1 < jn * 16u) {
+                    const uint32_t f = i1 & 15u, j = i1 >> 4;
+                    if (f < (uint32_t)TILE_SP_FIELDS) tab[f * PITCH + j] = pre1[u];
+                    if (f == 12u) lds_lx[(jb + j) * 2u] = pre1[u];
+                    if (f == 13u) lds_lx[(jb + j) * 2u + 1u] = pre1[u];
                 }
             }
-            __syncthreads();
-            if (tid >= gb && tid < gb + gcount) {
-                const float* vrow = lds_val + (tid - gb) * PITCH;
-                uint32_t k = 0;
-                for (; k + 8u <= jn; k += 8u) {
-                    const float v0 = vrow[k], v1 = vrow[k + 1], v2 = vrow[k + 2], v3 = vrow[k + 3];
-                    const float v4 = vrow[k + 4], v5 = vrow[k + 5], v6 = vrow[k + 6], v7 = vrow[k + 7];
-                    sum += v0; sum += v1; sum += v2; sum += v3; sum += v4; sum += v5; sum += v6; sum += v7;
-                }
-                for (; k < jn; ++k) sum += vrow[k];
+            lds_barrier();
+            SPSTAMP(0);
+            // refill this slot with the block DEPTH ahead (global-memory latency is ~2 us: with one block in
+            // flight the thin late stages would run at one block per round trip)
+            if (g + DEPTH < g_end) {
+                const uint32_t njn = blocks[2u * (g + DEPTH) + 1u] & 0xffu;
+                const uint32_t* src = table + (size_t)blocks[2u * (g + DEPTH)] * 16u;
+                if (tid < njn * 16u) pre0[u] = src[tid];
+                if (tid + NT < njn * 16u) pre1[u] = src[tid + NT];
             }
-            if (gb + TILE_SP_GROUP < T) __syncthreads();   // the value buffer is reused by the next group
-        }
-        const bool stage_done = b + 1u == n_blocks;
-        if (stage_done) {
-            // 4. survivors: thread t < T holds window t's verdict; compact lds_q across the waves
-            const float threshold = stages[s].threshold;
-            const bool pass = tid < T && sum >= threshold;
-            const QEntry e = lds_q[tid < T ? tid : 0u];
-            const unsigned long long mask = __ballot(pass);
-            if (lane == 0) lds_cnt[1u + wib] = (uint32_t)__popcll(mask);
-            __syncthreads();   // every entry is in registers, every wave's count is published
-            uint32_t before = 0, total = 0;
+            // 2. verdict bits of the block
+            {
+                NodeRecDev r;
 #pragma unroll
-            for (uint32_t w = 0; w < TILE_WAVES; ++w) {
-                const uint32_t c = lds_cnt[1u + w];
-                before += w < wib ? c : 0u;
-                total += c;
+                for (int f = 0; f < TILE_SP_FIELDS; ++f) r[f] = tab[f * PITCH + (lane < jn ? lane : 0u)];
+                r[14] = 0u;
+                r[15] = 0u;
+                const float thr_node = __uint_as_float(r[11]);
+                for (uint32_t w = wib; w < T; w += TILE_WAVES) {
+                    const QEntry e = lds_q[w];   // broadcast
+                    const bool right = lane < jn && node_rect_sum(img, r, e.off) >= thr_node * e.var;
+                    const unsigned long long m = __ballot(right);
+                    if (lane == 0) lds_mask[w * MAXB + b] = m;
+                }
             }
-            if (pass) lds_q[before + mbcnt(mask)] = e;
-            if (tid == 0) lds_cnt[0] = total;
-            __syncthreads();
-            T = __builtin_amdgcn_readfirstlane(lds_cnt[0]);
-            sum = 0.0f;
-            if (T == 0u || ns >= n_stages) break;
-            if (COUNT && tid == 0) atomicAdd(a.stage_entered + ns, (unsigned long long)T);
+            ++g;
+            SPSTAMP(1);
+            if (b + 1u == nb) {   // last block of stage s (uniform)
+                lds_barrier();   // every verdict of the stage is in lds_mask
+                SPSTAMP(2);
+                // 3. ordered accumulation and the stage decision: thread t owns window t
+                float sum = 0.0f;
+                if (tid < T) {
+                    // per stump: sign-extend its verdict bit, pick left or right with and/xor, add — 4 VALU
+                    // operations on the serial chain instead of shift/and/compare/select/add
+                    const uint2* lx = reinterpret_cast<const uint2*>(lds_lx);
+                    uint32_t k0 = 0;
+                    for (uint32_t bb = 0; bb < nb; ++bb) {
+                        const uint32_t bjn = blocks[2u * (g - nb + bb) + 1u] & 0xffu;
+                        const unsigned long long m = lds_mask[tid * MAXB + bb];
+                        uint32_t half = (uint32_t)m;
+                        uint32_t k = 0;
+                        for (; k + 8u <= bjn; k += 8u) {
+                            if (k == 32u) half = (uint32_t)(m >> 32);
+                            const uint32_t bits = half >> (k & 31u);
+                            uint2 v[8];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) v[q] = lx[k0 + k + q];
+#pragma unroll
+                            for (int q = 0; q < 8; ++q) {
+                                const uint32_t ext = (uint32_t)(((int32_t)(bits << (31 - q))) >> 31);   // v_bfe_i32
+                                sum += __uint_as_float(v[q].x ^ ((v[q].x ^ v[q].y) & ext));
+                            }
+                        }
+                        for (; k < bjn; ++k) {
+                            const uint2 v = lx[k0 + k];
+                            sum += (m >> k) & 1ull ? __uint_as_float(v.y) : __uint_as_float(v.x);
+                        }
+                        k0 += bjn;
+                    }
+                }
+                SPSTAMP(3);
+                // 4. survivors: compact lds_q across the waves
+                const bool pass = tid < T && sum >= stages[s].threshold;
+                const QEntry e = lds_q[tid < T ? tid : 0u];
+                const unsigned long long mask = __ballot(pass);
+                if (lane == 0) lds_cnt[1u + wib] = (uint32_t)__popcll(mask);
+                lds_barrier();   // every entry is in registers, every wave's count is published
+                uint32_t before = 0, total = 0;
+#pragma unroll
+                for (uint32_t w = 0; w < TILE_WAVES; ++w) {
+                    const uint32_t c = lds_cnt[1u + w];
+                    before += w < wib ? c : 0u;
+                    total += c;
+                }
+                if (pass) lds_q[before + mbcnt(mask)] = e;
+                T = __builtin_amdgcn_readfirstlane(total);
+                lds_barrier();   // lds_q is repacked; lds_cnt / lds_mask / lds_lr may be rewritten
+                SPSTAMP(4);
+                if (T == 0u || s + 1u >= n_stages) { SPFLUSH(); return T; }
+                if (COUNT && tid == 0) atomicAdd(a.stage_entered + s + 1u, (unsigned long long)T);
+            }
         }
-        __syncthreads();   // lds_val / lds_tab / lds_cnt are rewritten by the next block
-        s = ns; b = nb; jb = njb; S = nS; first_node = nfirst; n_blocks = nnb; jn = njn;
     }
-    return T;
 }
 
 template <bool TREES, bool COUNT>
@@ -688,6 +737,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
     const uint32_t total_units = a.n_tile_units * a.n_frames;
     const uint32_t frame_bytes4 = a.frame_elems * 4u;
 
+#define STAMP(ph) do { if (VJ_STAMPS && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(a.stage_entered + 40 + (ph), t_ - t_last); t_last = t_; } } while (0)
+    unsigned long long t_last = __builtin_amdgcn_s_memtime();
     for (uint32_t u = blockIdx.x; u < total_units; u += gridDim.x) {
         const uint32_t frame = u / a.n_tile_units;
         const uint32_t r = u - frame * a.n_tile_units;
@@ -705,57 +756,92 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         const uint32_t y0 = __builtin_amdgcn_readfirstlane((uint32_t)__float2int_rn((float)iy0 * step));
 
         __syncthreads();  // the previous tile's gathers are finished
+        STAMP(0);
         // stage the tile: rows round-robin over the waves, 64 consecutive dwords per instruction,
         // straight into LDS (buffer_load ... lds: no VGPR round trip, so every load of the tile is in
         // flight at once instead of one load-wait-store per 256 bytes); the barrier drains them
+        const uint32_t half = scales[slot].tile_half;
         for (uint32_t rr = wib; rr < rows; rr += TILE_WAVES) {
             const uint32_t g_row = ((y0 + rr) * a.stride + x0) * 4u;   // uniform
-            for (uint32_t c0 = 0; c0 < pitch; c0 += 64u) {
-                const uint32_t soff = __builtin_amdgcn_readfirstlane(g_row + c0 * 4u);   // keep it scalar
-                if (c0 + lane < pitch)
-                    __builtin_amdgcn_raw_ptr_buffer_load_lds(
-                        sum_f, (__attribute__((address_space(3))) uint32_t*)(lds_img + rr * pitch + c0), 4,
-                        lane * 4u, soff, 0, 0);
+            if (half == 0u) {
+                for (uint32_t c0 = 0; c0 < pitch; c0 += 64u) {
+                    const uint32_t soff = __builtin_amdgcn_readfirstlane(g_row + c0 * 4u);   // keep it scalar
+                    if (c0 + lane < pitch)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            sum_f, (__attribute__((address_space(3))) uint32_t*)(lds_img + rr * pitch + c0), 4,
+                            lane * 4u, soff, 0, 0);
+                }
+            } else {
+                // de-interleave while staging: plane 0 takes image columns 0, 2, 4, ..., plane 1 the odd ones
+                // (LDS destinations stay lane-contiguous, the sources are 8 bytes apart)
+                for (uint32_t plane = 0; plane < 2u; ++plane) {
+                    const uint32_t n_cols = plane == 0u ? half : pitch - half;
+                    for (uint32_t c0 = 0; c0 < n_cols; c0 += 64u) {
+                        const uint32_t soff = __builtin_amdgcn_readfirstlane(g_row + (c0 * 2u + plane) * 4u);
+                        if (c0 + lane < n_cols)
+                            __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                                sum_f,
+                                (__attribute__((address_space(3))) uint32_t*)(lds_img + rr * pitch + plane * half + c0), 4,
+                                lane * 8u, soff, 0, 0);
+                    }
+                }
+            }
+        }
+        // while the tile is in flight: this wave's share of the tile's tw*th windows (a run of consecutive
+        // tile-local indices, at least one full wave per wave), their positions, and the four squared-sum
+        // corners of each (HBM, 8 bytes per lane) — all issued before the barrier that drains the staging
+        q = lds_q + wib * TILE_WAVE_CAP;   // (re-packing below moves the wave's queue base)
+        const uint32_t n_tile = tw * th;
+        const uint32_t per_wave = max(64u, (n_tile + TILE_WAVES - 1u) / TILE_WAVES);   // <= TILE_WAVE_CAP (host)
+        const uint32_t t_begin = min(wib * per_wave, n_tile), t_end = min(t_begin + per_wave, n_tile);
+        const uint32_t te_lt = scales[slot].te_lt * 4u, te_dh = scales[slot].te_dh * 4u, e_dw = scales[slot].e_dw;
+        const uint32_t te_dw = (uint32_t)scales[slot].te_dw * 4u;
+        const uint32_t e_lt = scales[slot].e_lt, e_dh = scales[slot].e_dh;
+        const float area = scales[slot].area;
+        constexpr int NCH = TILE_WAVE_CAP / 64;
+        uint32_t w_lo4[NCH];
+        uint64_t w_q[NCH];
+        bool w_valid[NCH];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const uint32_t t = t_begin + (uint32_t)k * 64u + lane;
+            const uint32_t ty = t / tw, tx = t - ty * tw;
+            const uint32_t iy = iy0 + ty, ix = ix0 + tx;
+            w_valid[k] = t < t_end && iy < ny && ix < nx;
+            w_lo4[k] = 0u;
+            w_q[k] = 0ull;
+            if (w_valid[k]) {
+                const uint32_t x = (uint32_t)__float2int_rn((float)ix * step);
+                const uint32_t y = (uint32_t)__float2int_rn((float)iy * step);
+                // byte offset inside the tile (de-interleaved rows: window origins are even columns)
+                w_lo4[k] = ((y - y0) * pitch + (half ? (x - x0) >> 1 : x - x0)) * 4u;
+                const uint32_t e = y * a.stride + x;
+                const uint32_t c0 = e_lt, c1 = e_lt + e_dw, c2 = e_lt + e_dh, c3 = e_lt + e_dh + e_dw;
+                w_q[k] = ld_u64(sq_f, e * 8u, c0 * 8u) - ld_u64(sq_f, e * 8u, c1 * 8u) - ld_u64(sq_f, e * 8u, c2 * 8u) +
+                         ld_u64(sq_f, e * 8u, c3 * 8u);
             }
         }
         __syncthreads();
+        STAMP(1);
 
-        q = lds_q + wib * TILE_WAVE_CAP;   // (re-packing below moves the wave's queue base)
-        // this wave's share of the tile's tw*th windows: a run of consecutive tile-local indices
-        const uint32_t n_tile = tw * th;
-        // at least one full wave of windows per wave (small tiles leave the last waves idle)
-        const uint32_t per_wave = max(64u, (n_tile + TILE_WAVES - 1u) / TILE_WAVES);   // <= TILE_WAVE_CAP (host)
-        const uint32_t t_begin = min(wib * per_wave, n_tile), t_end = min(t_begin + per_wave, n_tile);
+        // computeVariance (clod.cpp:418-446): pixel sum from the LDS tile, squared sum as loaded above
         uint32_t n = 0;
-        const uint32_t te_lt = scales[slot].te_lt * 4u, te_dh = scales[slot].te_dh * 4u, e_dw = scales[slot].e_dw;
-        const uint32_t e_lt = scales[slot].e_lt, e_dh = scales[slot].e_dh;
-        const float area = scales[slot].area;
         const LdsImg img{reinterpret_cast<const char*>(lds_img)};
-        for (uint32_t t0 = t_begin; t0 < t_end; t0 += 64u) {
-            const uint32_t t = t0 + lane;
-            const uint32_t ty = t / tw, tx = t - ty * tw;
-            const uint32_t iy = iy0 + ty, ix = ix0 + tx;
-            const bool valid = t < t_end && iy < ny && ix < nx;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
             QEntry en{0u, 0.0f};
-            if (valid) {
-                const uint32_t x = (uint32_t)__float2int_rn((float)ix * step);
-                const uint32_t y = (uint32_t)__float2int_rn((float)iy * step);
-                const uint32_t lo4 = ((y - y0) * pitch + (x - x0)) * 4u;   // byte offset inside the tile
-                // computeVariance (clod.cpp:418-446): pixel sum from the LDS tile, squared sum from HBM
-                const uint32_t s4 = img.ld(lo4, te_lt) - img.ld(lo4, te_lt + e_dw * 4u) - img.ld(lo4, te_lt + te_dh) +
-                                    img.ld(lo4, te_lt + te_dh + e_dw * 4u);
-                const uint32_t e = y * a.stride + x;
-                const uint32_t c0 = e_lt, c1 = e_lt + e_dw, c2 = e_lt + e_dh, c3 = e_lt + e_dh + e_dw;
-                const uint64_t q4 = ld_u64(sq_f, e * 8u, c0 * 8u) - ld_u64(sq_f, e * 8u, c1 * 8u) -
-                                    ld_u64(sq_f, e * 8u, c2 * 8u) + ld_u64(sq_f, e * 8u, c3 * 8u);
+            if (w_valid[k]) {
+                const uint32_t lo4 = w_lo4[k];
+                const uint32_t s4 = img.ld(lo4, te_lt) - img.ld(lo4, te_lt + te_dw) - img.ld(lo4, te_lt + te_dh) +
+                                    img.ld(lo4, te_lt + te_dh + te_dw);
                 const float mean = (a.signed_mean ? (float)(int32_t)s4 : (float)s4) / area;
-                float variance = (float)q4;
+                float variance = (float)w_q[k];
                 variance = (variance / area) - (mean * mean);
                 en.var = variance >= 0.0f ? sqrtf(variance) : 1.0f;
                 en.off = lo4;
             }
-            const unsigned long long mask = __ballot(valid);
-            if (valid) q[n + mbcnt(mask)] = en;
+            const unsigned long long mask = __ballot(w_valid[k]);
+            if (w_valid[k]) q[n + mbcnt(mask)] = en;
             n += (uint32_t)__popcll(mask);
         }
         __builtin_amdgcn_wave_barrier();
@@ -766,6 +852,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         // At a pass boundary the whole workgroup leaves — handing its survivors to that pass's
         // queue — when the boundary lies at or beyond tile_end or fewer than tile_min_lanes
         // windows are left in the tile (the queue passes re-pack windows of the whole batch).
+        STAMP(2);
         uint32_t dest = a.n_pass;   // n_pass = ran the whole cascade: survivors are detections
         uint32_t next_p = 1;        // next pass boundary index
         const uint32_t n_stages_total = a.pass_begin[a.n_pass];
@@ -798,15 +885,17 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                 const uint32_t first = min(wib * share, total);
                 q = lds_q + first;
                 n = min(share, total - first);
+                STAMP(3 + min(st, 8u));   // time of stage st-1 (incl. waiting for the slowest wave) + this re-pack
                 if (!TREES && st >= a.tile_sp_begin && total != 0u && total <= a.tile_sp_max) {
                     // few windows left: finish the whole cascade stump-parallel; survivors are detections
                     const uint32_t left = tile_stump_parallel<COUNT>(
                         a, img, a.table + (size_t)scales[slot].tile_table_first * 16u, lds_q,
-                        reinterpret_cast<float*>(lds_q + TILE_SP_MAX_WINDOWS), lds_tab, lds_cnt, total, st, n_stages_total,
-                        lane, wib);
+                        reinterpret_cast<unsigned long long*>(lds_q + TILE_SP_MAX_WINDOWS), lds_tab, lds_cnt, total, st,
+                        n_stages_total, lane, wib, t_last);
                     q = lds_q;
                     n = wib == 0u ? left : 0u;
                     dest = a.n_pass;
+                    STAMP(12);
                     break;
                 }
                 if (at_boundary) {
@@ -831,7 +920,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
             for (uint32_t i = lane; i < n; i += 64u) {
                 const QEntry e = q[i];
                 const uint32_t lo = e.off >> 2;
-                const uint32_t ly = lo / pitch, lx = lo - ly * pitch;
+                const uint32_t ly = lo / pitch, lc = lo - ly * pitch;
+                const uint32_t lx = half ? lc * 2u : lc;   // window origins sit in the even plane
                 const uint32_t off = frame_bytes + ((y0 + ly) * a.stride + (x0 + lx)) * 4u;
                 if (is_det) {
                     if (g + i < a.det_cap) a.det[g + i] = DetEntry{off, slot};
@@ -840,6 +930,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                 }
             }
         }
+        STAMP(13);
         __builtin_amdgcn_wave_barrier();
     }
 }

@@ -60,12 +60,18 @@ std::vector<vj_scale_info> plan_scales(const vj_cascade& c, int W, int H, const 
 // precomputeKernelCascade (clod.cpp:529-578) for every node of the cascade, in flat
 // node order, into the 64-byte device record.
 int build_node_table(const vj_cascade& c, int width, const vj_scale_info& s, NodeRec* recs) {
-    return build_node_table_stride(c, (uint32_t)width + 1u, s, recs);
+    return build_node_table_stride(c, (uint32_t)width + 1u, s, recs, 0u);
 }
 
 // Same records with the row stride of some other image layout (the LDS tiles of the
 // tile kernel have their own pitch); weights and thresholds do not depend on it.
-int build_node_table_stride(const vj_cascade& c, uint32_t stride, const vj_scale_info& s, NodeRec* recs) {
+// deint_half != 0: the rows of that layout are de-interleaved — even columns first, odd
+// columns from element deint_half on — so column c sits at (c & 1) * deint_half + (c >> 1);
+// the left->right distance of a rectangle then depends on the parities and may be negative
+// (dw is a signed 16-bit field).
+int build_node_table_stride(const vj_cascade& c, uint32_t stride, const vj_scale_info& s, NodeRec* recs,
+                            uint32_t deint_half) {
+    auto col = [deint_half](uint32_t cx) { return deint_half ? (cx & 1u) * deint_half + (cx >> 1) : cx; };
     const float cs = s.scale;
     const float area = (float)s.area;
     for (size_t t = 0; t < c.trees.size(); ++t) {
@@ -94,15 +100,16 @@ int build_node_table_stride(const vj_cascade& c, uint32_t stride, const vj_scale
                     const uint32_t rw = round_u32((float)nd.rect[q].w * cs);
                     const uint32_t rh = round_u32((float)nd.rect[q].h * cs);
                     const float wgt = ow / area;
-                    const uint64_t lt = ((uint64_t)ry * stride + rx) * 4u;
+                    const uint64_t lt = ((uint64_t)ry * stride + col(rx)) * 4u;
                     const uint64_t dh = (uint64_t)rh * stride * 4u;
-                    if (lt > 0xffffffffull || dh > 0xffffffffull || rw * 4u > 0xffffu) {
+                    const int64_t dwb = ((int64_t)col(rx + rw) - (int64_t)col(rx)) * 4;
+                    if (lt > 0xffffffffull || dh > 0xffffffffull || dwb > 32767 || dwb < -32768) {
                         set_error("feature offsets exceed the device record range");
                         return VJ_ERR_LIMIT;
                     }
                     r.lt[q] = (uint32_t)lt;
                     r.dh[q] = (uint32_t)dh;
-                    dw[q] = rw * 4u;
+                    dw[q] = (uint32_t)dwb & 0xffffu;   // signed 16-bit
                     r.w[q] = wgt;
                     if (q > 0)
                         sum_rect_area += wgt * (float)rw * (float)rh;

@@ -106,6 +106,10 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
             r = env.detect(c, frames, p)
             assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, b
         env.configure("blocks_per_cu", 8)
+        env.configure("tile_deinterleave", 0)
+        r = env.detect(c, frames, p)
+        assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
+        env.configure("tile_deinterleave", 1)
         env.configure("concurrent", 1)
         r = env.detect(c, frames, p)
         assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
