@@ -45,6 +45,9 @@ def main() -> int:
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cascade", default="frontalface_alt")
     ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the batch timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the N > 1 path on a box with fewer GPUs than ranks)")
+    ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
     ap.add_argument("--pass-split", default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     args = ap.parse_args()
@@ -63,11 +66,17 @@ def main() -> int:
     if not torch.cuda.is_available():
         print("bench.py: no GPU visible; the HIP path has no CPU fallback", file=sys.stderr)
         return 3
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(args.backend, rank=rank, world_size=world)
+    coll_dev = dev if args.backend == "nccl" else torch.device("cpu")   # where the collectives' tensors live
 
     from clfacedetection_amd import (VJ_FLAG_COUNTERS, Cascade, DeviceFrames, Environment, default_params, multigpu,
                                      synth)
@@ -93,7 +102,7 @@ def main() -> int:
         if world > 1:
             rects = rects.copy()
             rects["frame"] += rank * B          # global frame index
-            rects = multigpu.allgather_rects(rects, device=dev)
+            rects = multigpu.allgather_rects(rects, device=coll_dev)
         return r, rects
 
     def barrier():
@@ -126,7 +135,7 @@ def main() -> int:
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -187,6 +196,7 @@ def main() -> int:
 
         # ---- CPU baseline: the oracle, 1 thread, on the first --cpu-frames frames (also a parity check)
         cpu = None
+        cpu_mt = None
         parity = None
         if world == 1 and args.cpu_frames > 0:
             from oracle.oracle import Oracle, load_vjc
@@ -206,6 +216,15 @@ def main() -> int:
             cpu = {"value": round(windows_per_frame * n_cpu / cpu_s, 1), "unit": "windows/s", "cores": 1,
                    "kind": "port", "sample": f"first {n_cpu} of the {B} frames, {cpu_s:.1f} s, oracle/vj_oracle.c "
                    f"(gcc -O2 -ffp-contract=off, integral + all scales + all stages)"}
+            # the same oracle on every host core the box gives us (one frame per thread; ctypes drops the GIL)
+            from concurrent.futures import ThreadPoolExecutor
+            n_thr = max(1, min(len(os.sched_getaffinity(0)), B))
+            t2 = time.perf_counter()
+            with ThreadPoolExecutor(n_thr) as ex:
+                list(ex.map(lambda f: o.detect(a, frames_h[f]), range(n_thr)))
+            mt_s = time.perf_counter() - t2
+            cpu_mt = {"value": round(windows_per_frame * n_thr / mt_s, 1), "unit": "windows/s", "cores": n_thr,
+                      "kind": "port", "sample": f"{n_thr} frames, one per thread, {mt_s:.1f} s"}
         out = {
             "metric": "candidate windows/sec, 1080p, haarcascade_frontalface_alt",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -229,7 +248,7 @@ def main() -> int:
                                   "frac": round(13 * W * H * B / (integral_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "stump_evals_per_window": round(counted.stump_evals / max(counted.windows, 1), 3),
             "cascade_algorithmic_GBps": round(counted.gather_bytes / (cascade_ms / K * 1e-3) / 1e9, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "parity_sample_ok": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt, "parity_sample_ok": parity,
         }
     if world > 1:
         dist.barrier()

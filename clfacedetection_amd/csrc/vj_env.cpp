@@ -92,6 +92,8 @@ struct vj_env {
     hipEvent_t launch_ev[2 * VJ_MAX_LAUNCHES] = {};   // start/stop per launch
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     hipStream_t stream2 = nullptr;   // second chain of the first part of the cascade
+    int max_subbatch = 0;      // > 0: cap on frames per sub-batch (tests)
+    uint32_t det_cap_init = 1u << 16;  // initial capacity of the detection buffer (grows on overflow)
     int concurrent = 0;   // measured: no gain (tile workgroups fill the LDS, the two chains serialise anyway)
     char name[256] = "";
     int n_cu = 0;
@@ -564,7 +566,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
     const size_t counts_bytes = (MAX_PASSES * MAX_SCALES + 2) * sizeof(uint32_t) + VJ_MAX_STAGES * sizeof(uint64_t);
     if ((rc = e->d_counts.ensure(counts_bytes))) return rc;
     if (e->det_cap == 0) {
-        e->det_cap = 1u << 16;
+        e->det_cap = e->det_cap_init;
         if ((rc = e->d_det.ensure((size_t)e->det_cap * sizeof(DetEntry)))) return rc;
     }
     uint32_t* d_qcount[MAX_PASSES];
@@ -960,6 +962,21 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         drop_plans(e);
         return VJ_OK;
     }
+    if (strcmp(key, "max_subbatch") == 0) {
+        e->max_subbatch = std::max(0, atoi(value));
+        return VJ_OK;
+    }
+    if (strcmp(key, "det_cap") == 0) {  // (re)sets the detection buffer capacity; it still grows on overflow
+        const int v = atoi(value);
+        if (v < 1) {
+            set_error("det_cap must be >= 1");
+            return VJ_ERR_ARG;
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->det_cap_init = (uint32_t)v;
+        e->det_cap = 0;
+        return VJ_OK;
+    }
     if (strcmp(key, "concurrent") == 0) {  // 1: tile launches and the global first pass overlap on two streams
         e->concurrent = atoi(value) != 0;
         return VJ_OK;
@@ -1054,6 +1071,7 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
     if (pl->windows_per_frame)
         max_frames = std::min<uint64_t>(max_frames, std::max<uint64_t>(1, q_budget / (pl->windows_per_frame * sizeof(QEntry))));
     max_frames = std::min<uint64_t>(max_frames, std::max<uint64_t>(1, 0xffffffffull / std::max<uint64_t>(1, pl->windows_per_frame)));
+    if (e->max_subbatch > 0) max_frames = std::min<uint64_t>(max_frames, (uint64_t)e->max_subbatch);
     if (max_frames == 0) {
         set_error("a single frame exceeds the 32-bit offset range");
         return VJ_ERR_LIMIT;

@@ -276,6 +276,26 @@ def test_config5_two_cascades_on_rois(env, oracle, cascades):
     assert len(faces.rects) > 0 and n_rois > 0
 
 
+def test_subbatching_and_detection_buffer_growth(env, cascades):
+    """Batches are cut into sub-batches when offsets or queues would overflow, and the detection buffer
+    grows (the cascade passes are re-run) when it overflows: force both and compare with the plain run."""
+    c, _ = cascades("frontalface_alt")
+    frames = synth.batch(7, 300, 400, seed0=2000, kinds=("noise",))
+    p = default_params(flags=VJ_FLAG_COUNTERS)
+    base = env.detect(c, frames, p)
+    assert len(base.rects) >= 3
+    try:
+        env.configure("max_subbatch", 3)
+        env.configure("det_cap", 1)
+        r = env.detect(c, frames, p)
+        assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
+        r = env.detect(c, frames, default_params())
+        assert np.array_equal(r.rects, base.rects)
+    finally:
+        env.configure("max_subbatch", 0)
+        env.configure("det_cap", 65536)
+
+
 def test_native_library_is_the_one_running(env):
     """The GPU tests must run hand-written HIP: libvjhip.so is mapped into this process."""
     maps = open("/proc/self/maps").read()
