@@ -50,8 +50,11 @@ struct StageDev {
     uint32_t n_trees;
     uint32_t order;        // stage-tree sweep: the i-th record holds the i-th stage to visit (topological)
     uint32_t sp_first;     // stump-parallel finish: index of the stage's first block in CascadeArgs::sp_blocks
+    float    sp_delta;     // ... |tree-order stage sum - sequential stage sum| <= sp_delta for ANY window (see
+                           //     tile_stump_parallel): 4 * n * 2^-24 * sum_k max(|left_k|, |right_k|), rounded up
+    uint32_t pad[3];
 };
-static_assert(sizeof(StageDev) == 32, "StageDev is 32 bytes");
+static_assert(sizeof(StageDev) == 48, "StageDev is 48 bytes");
 
 // One unit of first-pass work inside a frame: a run of consecutive windows of one scale.
 struct UnitDev {
@@ -91,7 +94,7 @@ constexpr int TILE_W = 64;           // windows per tile row (= lanes of a wave)
 constexpr int TILE_WAVE_CAP = 256;    // windows (= LDS queue entries) per wave of the tile kernel
 constexpr int TILE_CLASSES = 3;       // LDS size classes, one launch each
 constexpr int TILE_LDS_HEADER = (TILE_WAVES * TILE_WAVE_CAP * 2 + 32) * 4;  // queues + per-wave counts, bytes
-constexpr int TILE_SP_MAX_WINDOWS = 384;  // windows a tile may carry into the stump-parallel finish (one per thread)
+constexpr int TILE_SP_MAX_WINDOWS = 256;  // windows a tile may carry into the finish: entries + verdict masks + partial sums fit the 16 KiB queue area
 constexpr int TILE_SP_MAX_BLOCKS = 4;     // blocks of 64 stumps per stage at most (stages of <= 256 nodes)
 constexpr int TILE_SP_BLOCK = 64;         // stumps evaluated per round and window (= lanes of a wave)
 constexpr int TILE_SP_FIELDS = 14;        // dwords of a node record kept in the LDS copy of a stage's table

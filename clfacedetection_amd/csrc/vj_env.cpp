@@ -10,6 +10,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -348,6 +349,21 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         sd.on_fail = pl->prog.on_fail[s];
         sd.n_trees = (uint32_t)c.stages[s].n_trees;
         sd.order = s < order.size() ? order[s] : 0u;
+        {   // rigorous bound on how far two summation orders of this stage's leaf values can differ:
+            // every order satisfies |fl_sum - exact| <= gamma_{n-1} * sum|a_k| (Higham), gamma_k = k u / (1 - k u),
+            // u = 2^-24, and |a_k| <= max(|left_k|, |right_k|); the factor 4 (instead of 2) also covers the
+            // rounding of the comparison itself
+            double amax = 0.0;
+            const vj_stage_desc& st = c.stages[s];
+            for (int t = 0; t < st.n_trees; ++t) {
+                const vj_tree_desc& td = c.trees[st.first_tree + t];
+                double m = 0.0;
+                for (int k = 0; k <= td.n_nodes; ++k) m = std::max(m, (double)std::fabs(c.alpha[td.first_alpha + k]));
+                amax += m;
+            }
+            const double n = (double)pl->prog.n_nodes[s];
+            sd.sp_delta = (float)(4.0 * n * std::ldexp(1.0, -24) * amax * 1.001 + 1e-30);
+        }
         pl->stages.push_back(sd);
     }
     pl->n_order = (uint32_t)order.size();

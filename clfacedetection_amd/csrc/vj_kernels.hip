@@ -13,6 +13,7 @@
 // the reference's order.  This file MUST be compiled with -ffp-contract=off; HIP's
 // default correctly-rounded f32 divide/sqrt is relied upon.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "vj_device.hpp"
 
 #ifndef VJ_STAMPS
@@ -51,6 +52,23 @@ __device__ __forceinline__ uint32_t ld_u32(rsrc_t r, uint32_t lane_off, uint32_t
 __device__ __forceinline__ uint64_t ld_u64(rsrc_t r, uint32_t lane_off, uint32_t uniform_off) {
     const auto v = __builtin_amdgcn_raw_buffer_load_b64(r, lane_off, uniform_off, 0);
     return (uint64_t)v[0] | ((uint64_t)v[1] << 32);
+}
+
+// Sum of a float over the 64 lanes, left in lane 63, with DPP adds only (no LDS crossbar traffic):
+// butterflies inside quads and rows of 16, then row_bcast15 / row_bcast31 across the rows.  The
+// order of the additions is NOT lane order — callers must not need that.
+__device__ __forceinline__ float wave_sum_to_lane63(float v) {
+    auto dpp = [](float x, auto ctrl, auto row_mask) {
+        return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(x), decltype(ctrl)::value, decltype(row_mask)::value, 0xf, true));
+    };
+    using std::integral_constant;
+    v += dpp(v, integral_constant<int, 0xB1>{}, integral_constant<int, 0xf>{});    // quad_perm [1,0,3,2]
+    v += dpp(v, integral_constant<int, 0x4E>{}, integral_constant<int, 0xf>{});    // quad_perm [2,3,0,1]
+    v += dpp(v, integral_constant<int, 0x141>{}, integral_constant<int, 0xf>{});   // row_half_mirror
+    v += dpp(v, integral_constant<int, 0x140>{}, integral_constant<int, 0xf>{});   // row_mirror
+    v += dpp(v, integral_constant<int, 0x142>{}, integral_constant<int, 0xa>{});   // row_bcast15 -> rows 1, 3
+    v += dpp(v, integral_constant<int, 0x143>{}, integral_constant<int, 0xc>{});   // row_bcast31 -> rows 2, 3
+    return v;
 }
 
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains every outstanding
@@ -596,6 +614,7 @@ __device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, co
     constexpr int DEPTH = 4;                                         // record blocks in flight from global memory
     uint32_t* lds_tab = lds_sp;                                      // two buffers of TABSZ dwords
     uint32_t* lds_lx = lds_sp + 2u * TABSZ;   // {left, right} bit patterns of every stump of the stage
+    float* lds_part = reinterpret_cast<float*>(lds_mask + TILE_SP_MAX_WINDOWS * MAXB);   // butterfly partial sums
     const uint32_t g_end = a.n_sp_blocks;
     uint32_t g = stages[st_begin].sp_first;   // running block number over all stages
     // records of block x: 16 dwords per node, thread t fetches dwords t and t + 512 of the block
@@ -654,11 +673,19 @@ __device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, co
                 r[14] = 0u;
                 r[15] = 0u;
                 const float thr_node = __uint_as_float(r[11]);
+                const float leaf_l = lane < jn ? __uint_as_float(r[12]) : 0.0f;
+                const float leaf_r = lane < jn ? __uint_as_float(r[13]) : 0.0f;
                 for (uint32_t w = wib; w < T; w += TILE_WAVES) {
                     const QEntry e = lds_q[w];   // broadcast
                     const bool right = lane < jn && node_rect_sum(img, r, e.off) >= thr_node * e.var;
                     const unsigned long long m = __ballot(right);
-                    if (lane == 0) lds_mask[w * MAXB + b] = m;
+                    // the block's leaf values summed across the lanes (DPP butterfly order — NOT the cascade's
+                    // order; it only feeds the fast decision below)
+                    const float part = wave_sum_to_lane63(right ? leaf_r : leaf_l);
+                    if (lane == 63) {
+                        lds_mask[w * MAXB + b] = m;
+                        lds_part[w * MAXB + b] = part;
+                    }
                 }
             }
             ++g;
@@ -666,40 +693,39 @@ __device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, co
             if (b + 1u == nb) {   // last block of stage s (uniform)
                 lds_barrier();   // every verdict of the stage is in lds_mask
                 SPSTAMP(2);
-                // 3. ordered accumulation and the stage decision: thread t owns window t
+                // 3. the stage decision: thread t owns window t.  The sequential stage sum (stage_sum += alpha in
+                // stump order, clod.cl:81) and the butterfly-order sum of the same values differ by at most
+                // sp_delta (a rigorous a-priori bound, computed per stage on the host), so when the butterfly sum
+                // clears the stage threshold by more than sp_delta either way the reference's comparison is
+                // decided; only the rare windows inside the band walk their verdict bits in stump order.
                 float sum = 0.0f;
+                bool decided_pass = false;
                 if (tid < T) {
-                    // per stump: sign-extend its verdict bit, pick left or right with and/xor, add — 4 VALU
-                    // operations on the serial chain instead of shift/and/compare/select/add
-                    const uint2* lx = reinterpret_cast<const uint2*>(lds_lx);
-                    uint32_t k0 = 0;
-                    for (uint32_t bb = 0; bb < nb; ++bb) {
-                        const uint32_t bjn = blocks[2u * (g - nb + bb) + 1u] & 0xffu;
-                        const unsigned long long m = lds_mask[tid * MAXB + bb];
-                        uint32_t half = (uint32_t)m;
-                        uint32_t k = 0;
-                        for (; k + 8u <= bjn; k += 8u) {
-                            if (k == 32u) half = (uint32_t)(m >> 32);
-                            const uint32_t bits = half >> (k & 31u);
-                            uint2 v[8];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) v[q] = lx[k0 + k + q];
-#pragma unroll
-                            for (int q = 0; q < 8; ++q) {
-                                const uint32_t ext = (uint32_t)(((int32_t)(bits << (31 - q))) >> 31);   // v_bfe_i32
-                                sum += __uint_as_float(v[q].x ^ ((v[q].x ^ v[q].y) & ext));
+                    float approx = 0.0f;
+                    for (uint32_t bb = 0; bb < nb; ++bb) approx += lds_part[tid * MAXB + bb];
+                    const float thr_s = stages[s].threshold, delta = stages[s].sp_delta;
+                    const float d = approx - thr_s;
+                    const bool clear = d > delta || d < -delta;
+                    decided_pass = d > delta;
+                    if (!clear) {
+                        // exact: sign-extend each verdict bit, pick left or right with and/xor, add in order
+                        const uint2* lx = reinterpret_cast<const uint2*>(lds_lx);
+                        uint32_t k0 = 0;
+                        for (uint32_t bb = 0; bb < nb; ++bb) {
+                            const uint32_t bjn = blocks[2u * (g - nb + bb) + 1u] & 0xffu;
+                            const unsigned long long m = lds_mask[tid * MAXB + bb];
+                            for (uint32_t k = 0; k < bjn; ++k) {
+                                const uint2 v = lx[k0 + k];
+                                sum += (m >> k) & 1ull ? __uint_as_float(v.y) : __uint_as_float(v.x);
                             }
+                            k0 += bjn;
                         }
-                        for (; k < bjn; ++k) {
-                            const uint2 v = lx[k0 + k];
-                            sum += (m >> k) & 1ull ? __uint_as_float(v.y) : __uint_as_float(v.x);
-                        }
-                        k0 += bjn;
+                        decided_pass = sum >= thr_s;
                     }
                 }
                 SPSTAMP(3);
                 // 4. survivors: compact lds_q across the waves
-                const bool pass = tid < T && sum >= stages[s].threshold;
+                const bool pass = tid < T && decided_pass;
                 const QEntry e = lds_q[tid < T ? tid : 0u];
                 const unsigned long long mask = __ballot(pass);
                 if (lane == 0) lds_cnt[1u + wib] = (uint32_t)__popcll(mask);

@@ -124,7 +124,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
             env.configure("tile_min_lanes", {3: 0, 10: 12, 22: 64, 14: 1, 7: 200}[tile_end])
             env.configure("tile_repack", {3: "", 10: "3,5", 22: "1,2,3,4,5,6,7,9,11,13,17", 14: "2", 7: "6"}[tile_end])
             env.configure("tile_sp_begin", {3: 64, 10: 8, 22: 4, 14: 1, 7: 6}[tile_end])
-            env.configure("tile_sp_max", {3: 96, 10: 48, 22: 512, 14: 200, 7: 45}[tile_end])
+            env.configure("tile_sp_max", {3: 96, 10: 48, 22: 256, 14: 200, 7: 45}[tile_end])
             for split in ("", "22", "7", "2,4,6,9,12,15,18"):
                 env.configure("pass_split", split)
                 r = env.detect(c, frames, p)
