@@ -119,7 +119,7 @@ struct vj_env {
     int tile_end = 12;            // tile launches never enter a pass that begins at or beyond this stage
     int tile_min_lanes = 0;       // a tile leaves at a pass boundary when fewer windows than this survive in it
     unsigned long long tile_repack_mask = 0x3ffffcull;  // stages (2..21) before which a tile re-packs its survivors
-    int tile_sp_begin = 4;        // first stage at which a tile may switch to the stump-parallel finish (>= 64: never)
+    int tile_sp_begin = 3;        // first stage at which a tile may switch to the stump-parallel finish (>= 64: never)
     int tile_sp_max = 192;
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales        // ... once at most this many of its windows survive
     std::vector<int> split_override;

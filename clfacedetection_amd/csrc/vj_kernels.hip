@@ -675,7 +675,25 @@ __device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, co
                 const float thr_node = __uint_as_float(r[11]);
                 const float leaf_l = lane < jn ? __uint_as_float(r[12]) : 0.0f;
                 const float leaf_r = lane < jn ? __uint_as_float(r[13]) : 0.0f;
-                for (uint32_t w = wib; w < T; w += TILE_WAVES) {
+                // two windows per iteration: their gathers are independent, so the second window's LDS latency
+                // hides behind the first one's arithmetic
+                uint32_t w = wib;
+                for (; w + TILE_WAVES < T; w += 2u * TILE_WAVES) {
+                    const QEntry e0 = lds_q[w], e1 = lds_q[w + TILE_WAVES];   // broadcasts
+                    const float s0 = node_rect_sum(img, r, e0.off), s1 = node_rect_sum(img, r, e1.off);
+                    const bool right0 = lane < jn && s0 >= thr_node * e0.var;
+                    const bool right1 = lane < jn && s1 >= thr_node * e1.var;
+                    const unsigned long long m0 = __ballot(right0), m1 = __ballot(right1);
+                    const float part0 = wave_sum_to_lane63(right0 ? leaf_r : leaf_l);
+                    const float part1 = wave_sum_to_lane63(right1 ? leaf_r : leaf_l);
+                    if (lane == 63) {
+                        lds_mask[w * MAXB + b] = m0;
+                        lds_part[w * MAXB + b] = part0;
+                        lds_mask[(w + TILE_WAVES) * MAXB + b] = m1;
+                        lds_part[(w + TILE_WAVES) * MAXB + b] = part1;
+                    }
+                }
+                if (w < T) {
                     const QEntry e = lds_q[w];   // broadcast
                     const bool right = lane < jn && node_rect_sum(img, r, e.off) >= thr_node * e.var;
                     const unsigned long long m = __ballot(right);

@@ -138,7 +138,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("tile_min_windows", 768)
         env.configure("tile_min_lanes", 0)
         env.configure("tile_repack", ",".join(str(i) for i in range(2, 22)))
-        env.configure("tile_sp_begin", 4)
+        env.configure("tile_sp_begin", 3)
         env.configure("tile_sp_max", 192)
 
 

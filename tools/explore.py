@@ -70,12 +70,12 @@ if "b64" in what:
     env.configure("pass_split", ""); env.configure("tile_end", 8)
 if "sp" in what:
     rp_all = ",".join(str(i) for i in range(2, 22))
-    for spb, spm, sp, te in ((64, 96, "5,8", 8), (6, 48, "5,8,12", 12), (6, 96, "5,8,12", 12), (6, 192, "5,8,12", 12), (5, 96, "5,8,12", 12), (5, 192, "5,8,12", 12),
-                             (4, 192, "5,8,12", 12), (4, 512, "5,8,12", 12), (3, 512, "5,8,12", 12), (5, 256, "5,9", 9), (5, 512, "5,8,12", 12)):
+    for spb, spm, sp, te in ((4, 192, "5,8,13", 12), (4, 256, "5,8,13", 12), (3, 256, "5,8,13", 12), (3, 192, "5,8,13", 12), (2, 256, "5,8,13", 12), (5, 256, "5,8,13", 12),
+                             (4, 128, "5,8,13", 12), (4, 256, "5,8,13", 22), (4, 256, "5,13", 13)):
         env.configure("tile_sp_begin", spb); env.configure("tile_sp_max", spm); env.configure("tile_repack", rp_all); env.configure("pass_split", sp); env.configure("tile_end", te)
         r = run(default_params(), 2)
         print(f"sp_begin={spb} sp_max={spm} split={sp!r} tile_end={te}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{l['ms']:.1f}" for l in r.launches), flush=True)
-    env.configure("tile_sp_begin", 4); env.configure("tile_sp_max", 192); env.configure("tile_repack", ",".join(str(i) for i in range(2, 22))); env.configure("pass_split", ""); env.configure("tile_end", 12)
+    env.configure("tile_sp_begin", 3); env.configure("tile_sp_max", 192); env.configure("tile_repack", rp_all); env.configure("pass_split", ""); env.configure("tile_end", 12)
 if "large" in what:
     for acc, mdw in ((512, 600), (256, 600), (128, 600), (128, 1200), (64, 1200), (64, 2500), (32, 2500), (16, 5000)):
         env.configure("tile_accept_windows", acc); env.configure("tile_max_dwords_per_window", mdw)
