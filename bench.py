@@ -197,6 +197,7 @@ def main() -> int:
         # ---- CPU baseline: the oracle, 1 thread, on the first --cpu-frames frames (also a parity check)
         cpu = None
         cpu_mt = None
+        cpu_cv = None
         parity = None
         if world == 1 and args.cpu_frames > 0:
             from oracle.oracle import Oracle, load_vjc
@@ -225,6 +226,24 @@ def main() -> int:
             mt_s = time.perf_counter() - t2
             cpu_mt = {"value": round(windows_per_frame * n_thr / mt_s, 1), "unit": "windows/s", "cores": n_thr,
                       "kind": "port", "sample": f"{n_thr} frames, one per thread, {mt_s:.1f} s"}
+            # north_star's other CPU leg: the OpenCV-style scale-cascade path as tempcv.cpp keeps it (f64 sums,
+            # ystep = max(2, factor), stage-0 skip).  It visits fewer windows than clod by design, so its honest
+            # unit is frames/s; compare with this line's "frames_per_s".
+            t3 = time.perf_counter()
+            vis = 0
+            for f in range(n_cpu):
+                _, st_cv = o.detect_opencvlike(a, frames_h[f])
+                vis += st_cv["windows"]
+            cv_s = time.perf_counter() - t3
+            t4 = time.perf_counter()
+            with ThreadPoolExecutor(n_thr) as ex:
+                list(ex.map(lambda f: o.detect_opencvlike(a, frames_h[f]), range(n_thr)))
+            cvmt_s = time.perf_counter() - t4
+            cpu_cv = {"value": round(n_cpu / cv_s, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+                      "all_cores": {"value": round(n_thr / cvmt_s, 3), "unit": "frames/s", "cores": n_thr},
+                      "windows_visited_per_frame": vis // n_cpu,
+                      "sample": f"first {n_cpu} frames, {cv_s:.1f} s, oc_detect_opencvlike (restates tempcv.cpp "
+                                f"cvHaarDetectObjects; unpinned, timing only)"}
         out = {
             "metric": "candidate windows/sec, 1080p, haarcascade_frontalface_alt",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -248,7 +267,8 @@ def main() -> int:
                                   "frac": round(13 * W * H * B / (integral_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "stump_evals_per_window": round(counted.stump_evals / max(counted.windows, 1), 3),
             "cascade_algorithmic_GBps": round(counted.gather_bytes / (cascade_ms / K * 1e-3) / 1e9, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt, "parity_sample_ok": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
+            "cpu_baseline_opencvlike": cpu_cv, "parity_sample_ok": parity,
         }
     if world > 1:
         dist.barrier()

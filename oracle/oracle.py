@@ -250,6 +250,9 @@ class Oracle:
         L.oc_xorshift_noise.restype = None
         L.oc_u64_to_f32.argtypes = [C.c_uint64]
         L.oc_u64_to_f32.restype = C.c_float
+        L.oc_detect_opencvlike.argtypes = [C.POINTER(_OcCascade), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                           C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_OcStats)]
+        L.oc_detect_opencvlike.restype = C.c_int
         L.oc_group_rectangles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
         L.oc_group_rectangles.restype = C.c_int
 
@@ -330,6 +333,20 @@ class Oracle:
                  "gather_bytes": 48 * int(st.windows) + 16 * int(st.rect_evals),
                  "stage_entered": [int(v) for v in st.stage_entered[:c.n_stages]]}
         return r, stats
+
+    def detect_opencvlike(self, c: CascadeArrays, gray: np.ndarray, min_size=(0, 0), scale_factor: float = 1.1,
+                          cap: int = 1 << 20):
+        """cvHaarDetectObjects' scale-cascade path per tempcv.cpp (f64 sums, threshold bias, stage-0 skip):
+        a TIMED baseline only, not a parity target.  Returns (rects, stats)."""
+        h, w = gray.shape
+        g = np.ascontiguousarray(gray)
+        s, keep = self._cstruct(c)
+        out = np.zeros(cap, _RECT_DT)
+        n_total = C.c_int(0)
+        st = _OcStats()
+        n = self.lib.oc_detect_opencvlike(C.byref(s), g.ctypes.data, w, h, g.strides[0], min_size[0], min_size[1],
+                                          float(scale_factor), out.ctypes.data, cap, C.byref(n_total), C.byref(st))
+        return out[:n], {"windows": int(st.windows), "stump_evals": int(st.stump_evals)}
 
     # f1 (next row): grouping
     def group_rectangles(self, xywh: np.ndarray, group_threshold: int, eps: float = 0.2):

@@ -502,3 +502,125 @@ int oc_group_rectangles(oc_grect* rects, int n, int groupThreshold, double eps, 
     free(labels); free(rrects); free(rweights);
     return out;
 }
+
+/* ------------------------------------------- CPU baseline #2: the OpenCV-style path */
+/* Restatement of cvHaarDetectObjects' scale-cascade path as the reference keeps it in tempcv.cpp
+ * (a private copy of OpenCV 2.4.2 objdetect/haar.cpp, not part of the reference's build):
+ *   driver loop                       tempcv.cpp:1330-1417  (double factor, ystep = max(2, factor), cvRound)
+ *   cvSetImagesForHaarClassifierCascade   :549-768          (cvRound-ed rects, float weights, CV_ADJUST_WEIGHTS = 0)
+ *   cvRunHaarClassifierCascadeSum      :795-972             (f64 sums, border rule :817-820)
+ *   stage threshold bias               :262, :419           (threshold - 0.0001f)
+ *   ScaleCascade invoker               :1116-1185           (ixstep = result != 0 ? 1 : 2)
+ * This is the "reference CPU path (OpenCV cv::CascadeClassifier ...)" north_star asks to be TIMED as a
+ * baseline.  It is NOT a parity target: its arithmetic differs from the clod path on purpose, OpenCV itself
+ * is not installable here, so nothing pins it (SURVEY.md §8c "parity unpinned at the OpenCV boundary").   */
+typedef struct cv_rectp { int p0, p1, p2, p3; float weight; } cv_rectp;
+typedef struct cv_node { cv_rectp rect[3]; int nrect; float threshold; } cv_node;
+
+static inline int cv_round(double v) { return (int)lrint(v); }
+
+int oc_detect_opencvlike(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride,
+                         int min_w, int min_h, double scaleFactor,
+                         oc_rect* out, int cap, int* n_total, oc_stats* st) {
+    const int sw = W + 1;
+    int32_t* sum = (int32_t*)calloc((size_t)sw * (H + 3), sizeof(int32_t));
+    double* sqsum = (double*)calloc((size_t)sw * (H + 3), sizeof(double));
+    cv_node* kn = (cv_node*)malloc(sizeof(cv_node) * (size_t)c->n_nodes);
+    memset(st, 0, sizeof(*st));
+    oc_integral(gray, W, H, stride, sum, sqsum);
+    int found = 0, n_factors = 0, scale_index = 0;
+    double factor;
+    for (n_factors = 0, factor = 1; factor * c->win_w < W - 10 && factor * c->win_h < H - 10;
+         n_factors++, factor *= scaleFactor) {}
+    factor = 1;
+    for (; n_factors-- > 0; factor *= scaleFactor, scale_index++) {
+        const double ystep = 2. > factor ? 2. : factor;
+        const int win_w = cv_round(c->win_w * factor), win_h = cv_round(c->win_h * factor);
+        const int endX = cv_round((W - win_w) / ystep), endY = cv_round((H - win_h) / ystep);
+        if (win_w < min_w || win_h < min_h) continue;
+        /* cvSetImagesForHaarClassifierCascade */
+        const int ex = cv_round(factor), ew = cv_round((c->win_w - 2) * factor), eh = cv_round((c->win_h - 2) * factor);
+        const double weight_scale = 1. / (ew * eh);
+        const int q0 = ex * sw + ex, q1 = ex * sw + ex + ew, q2 = (ex + eh) * sw + ex, q3 = (ex + eh) * sw + ex + ew;
+        for (int n = 0; n < c->n_nodes; ++n) {
+            double sum0 = 0, area0 = 0;
+            int nr = 0;
+            while (nr < 3 && c->node_weight[n * 3 + nr] != 0) nr++;
+            kn[n].nrect = nr;
+            kn[n].threshold = c->node_threshold[n];
+            for (int k = 0; k < nr; ++k) {
+                const int32_t* r = c->node_rect + (n * 3 + k) * 4;
+                const int tx = cv_round(r[0] * factor), ty = cv_round(r[1] * factor);
+                const int tw = cv_round(r[2] * factor), th = cv_round(r[3] * factor);
+                kn[n].rect[k].p0 = ty * sw + tx;
+                kn[n].rect[k].p1 = ty * sw + tx + tw;
+                kn[n].rect[k].p2 = (ty + th) * sw + tx;
+                kn[n].rect[k].p3 = (ty + th) * sw + tx + tw;
+                kn[n].rect[k].weight = (float)(c->node_weight[n * 3 + k] * weight_scale);
+                if (k == 0) area0 = tw * th;
+                else sum0 += kn[n].rect[k].weight * tw * th;
+            }
+            kn[n].rect[0].weight = (float)(-sum0 / area0);
+        }
+        for (int iy = 0; iy < endY; iy++) {
+            const int y = cv_round(iy * ystep);
+            int ixstep = 1;
+            for (int ix = 0; ix < endX; ix += ixstep) {
+                const int x = cv_round(ix * ystep);
+                int result;
+                st->windows++;
+                if (x < 0 || y < 0 || x + win_w >= sw || y + win_h >= H + 1) {
+                    result = -1;
+                } else {
+                    const int po = y * sw + x;
+                    double mean = (double)(sum[po + q0] - sum[po + q1] - sum[po + q2] + sum[po + q3]) * weight_scale;
+                    double vnf = sqsum[po + q0] - sqsum[po + q1] - sqsum[po + q2] + sqsum[po + q3];
+                    vnf = vnf * weight_scale - mean * mean;
+                    vnf = vnf >= 0. ? sqrt(vnf) : 1.;
+                    int ptr = 0;
+                    result = 1;
+                    while (ptr != -1) {
+                        double stage_sum = 0.0;
+                        const int t0 = c->stage_first_tree[ptr], t1 = t0 + c->stage_n_trees[ptr];
+                        st->stage_entered[ptr]++;
+                        for (int t = t0; t < t1; ++t) {
+                            const int n0 = c->tree_first_node[t];
+                            const float* alpha = c->alpha + c->tree_first_alpha[t];
+                            int idx = 0;
+                            do {
+                                const cv_node* k = kn + n0 + idx;
+                                const double tt = k->threshold * vnf;
+                                double s = (double)(sum[po + k->rect[0].p0] - sum[po + k->rect[0].p1] - sum[po + k->rect[0].p2] +
+                                                    sum[po + k->rect[0].p3]) * k->rect[0].weight;
+                                s += (double)(sum[po + k->rect[1].p0] - sum[po + k->rect[1].p1] - sum[po + k->rect[1].p2] +
+                                              sum[po + k->rect[1].p3]) * k->rect[1].weight;
+                                if (k->nrect > 2)
+                                    s += (double)(sum[po + k->rect[2].p0] - sum[po + k->rect[2].p1] - sum[po + k->rect[2].p2] +
+                                                  sum[po + k->rect[2].p3]) * k->rect[2].weight;
+                                st->stump_evals++;
+                                idx = s < tt ? c->node_left[n0 + idx] : c->node_right[n0 + idx];
+                            } while (idx > 0);
+                            stage_sum += alpha[-idx];
+                        }
+                        if (stage_sum >= c->stage_threshold[ptr] - 0.0001f) {
+                            ptr = c->stage_child[ptr];
+                        } else {
+                            const int failed_at = ptr;
+                            while (ptr != -1 && c->stage_next[ptr] == -1) ptr = c->stage_parent[ptr];
+                            if (ptr == -1) { result = -failed_at; break; }   /* 0 when the first stage rejects */
+                            ptr = c->stage_next[ptr];
+                        }
+                    }
+                }
+                if (result > 0) {
+                    if (found < cap) { out[found].x = x; out[found].y = y; out[found].w = win_w; out[found].h = win_h; out[found].scale_idx = scale_index; }
+                    found++;
+                }
+                ixstep = result != 0 ? 1 : 2;
+            }
+        }
+    }
+    free(kn); free(sum); free(sqsum);
+    *n_total = found;
+    return found < cap ? found : cap;
+}

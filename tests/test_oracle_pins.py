@@ -105,3 +105,20 @@ def test_reference_is_not_buildable_here():
     r = subprocess.run([shutil.which("g++") or "g++", "-fsyntax-only", "-x", "c++",
                         "/root/reference/CLFaceDetection/clod.cpp"], capture_output=True, text=True)
     assert r.returncode != 0 and ("opencv2" in r.stderr or "CLEnvironment.h" in r.stderr)
+
+
+def test_opencvlike_baseline_sanity(oracle, cascades):
+    """The OpenCV-style restatement is a timing baseline only (unpinned); sanity: it walks fewer windows than
+    the clod grid (ystep >= 2, stage-0 skip), every hit is a legal window, and on the pinned 640x480 frame the
+    two arithmetic profiles agree on the two alt detections."""
+    from cases import make_frame
+    a = cascades("frontalface_alt")[1]
+    img = make_frame("xorshift", 12345, 480, 640, oracle)
+    r, st = oracle.detect_opencvlike(a, img)
+    r2, st2 = oracle.detect(a, img)
+    assert 0 < st["windows"] < st2["windows"]
+    assert all(0 <= x and x + w < 641 and 0 <= y and y + h < 481 for x, y, w, h in zip(r["x"], r["y"], r["w"], r["h"]))
+    assert sorted(zip(r["x"], r["y"], r["w"])) == sorted(zip(r2["x"], r2["y"], r2["w"]))
+    # min_size skips whole scales
+    r3, st3 = oracle.detect_opencvlike(a, img, min_size=(60, 60))
+    assert st3["windows"] < st["windows"] and all(w >= 60 for w in r3["w"])
