@@ -95,6 +95,7 @@ constexpr int TILE_WAVE_CAP = 256;    // windows (= LDS queue entries) per wave 
 constexpr int TILE_CLASSES = 3;       // LDS size classes, one launch each
 constexpr int TILE_LDS_HEADER = (TILE_WAVES * TILE_WAVE_CAP * 2 + 32) * 4;  // queues + per-wave counts, bytes
 constexpr int TILE_SP_MAX_WINDOWS = 256;  // windows a tile may carry into the finish: entries + verdict masks + partial sums fit the 16 KiB queue area
+constexpr int TILE_WS_MAX_WINDOWS = 512;  // wave-split finish: 8 chunks of packed entries (4 KiB) + 8 x 320 dwords of sums and verdict words
 constexpr int TILE_SP_MAX_BLOCKS = 4;     // blocks of 64 stumps per stage at most (stages of <= 256 nodes)
 constexpr int TILE_SP_BLOCK = 64;         // stumps evaluated per round and window (= lanes of a wave)
 constexpr int TILE_SP_FIELDS = 14;        // dwords of a node record kept in the LDS copy of a stage's table
@@ -110,6 +111,7 @@ struct CascadeArgs {
     const UnitDev*  tile_units; // first-pass tiles of ONE frame (LDS-tile scales): first = ix0 | iy0 << 16
     uint32_t n_tile_units;
     uint32_t tile_lds_bytes;    // dynamic LDS of the tile kernel
+    uint32_t* tile_ticket;      // next tile index - gridDim.x of this tile launch (zeroed before the launch)
     uint32_t n_frames;
     uint32_t n_scales;
     uint32_t frame_elems;       // elements per frame in sum / sqsum
@@ -137,6 +139,9 @@ struct CascadeArgs {
     uint32_t  tile_sp_begin;                // >= number of stages: disabled
     uint32_t  tile_sp_pad;                  // dwords of LDS reserved for the finish: two record blocks + leaf values (0 = off)
     uint32_t  tile_sp_max;                  // enter the finish when at most this many windows are left
+    uint32_t  tile_finish;                  // 0: stump-parallel finish, 1: wave-split finish (tile_wave_split)
+    uint32_t  tile_ws_min;                  // ... and hand over to the stump-parallel finish below this many
+    uint32_t  tile_ws_max;                  // enter the wave-split finish when at most this many windows are left
     const SpBlock* sp_blocks;               // per block of <= 64 stumps, all stages in order
     uint32_t  n_sp_blocks;
     DetEntry* det;              // detections (last pass)

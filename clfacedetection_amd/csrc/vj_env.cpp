@@ -95,7 +95,9 @@ struct vj_env {
     hipStream_t stream2 = nullptr;   // second chain of the first part of the cascade
     int max_subbatch = 0;      // > 0: cap on frames per sub-batch (tests)
     uint32_t det_cap_init = 1u << 16;  // initial capacity of the detection buffer (grows on overflow)
-    int concurrent = 0;   // measured: no gain (tile workgroups fill the LDS, the two chains serialise anyway)
+    int concurrent = 0;   // 1: the tile chain and the global-gather chain overlap on two streams
+    int concurrent_blocks_per_cu = 1;   // workgroups per CU of the global-gather chain while it overlaps
+    int tile_lds_reserve_kb = 0;        // LDS per CU the tile classes leave to the other chain
     char name[256] = "";
     int n_cu = 0;
     // image buffers
@@ -121,6 +123,9 @@ struct vj_env {
     unsigned long long tile_repack_mask = 0x3ffffcull;  // stages (2..21) before which a tile re-packs its survivors
     int tile_sp_begin = 3;        // first stage at which a tile may switch to the stump-parallel finish (>= 64: never)
     int tile_sp_max = 192;
+    int tile_finish = 1;          // 0: stump-parallel finish, 1: wave-split finish
+    int tile_ws_max = 512;
+    int tile_ws_min = 32;         // ... below this many the stump-parallel finish takes over        // windows a tile may carry into the wave-split finish
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales        // ... once at most this many of its windows survive
     std::vector<int> split_override;
 };
@@ -291,7 +296,8 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
             uint32_t best_cls = TILE_CLASSES, best_n = 0, b_tw = 0, b_th = 0, b_pitch = 0, b_rows = 0;
             for (uint32_t cls = 0; cls < TILE_CLASSES && best_n < (uint32_t)e->tile_min_windows; ++cls) {
                 const int kb = e->tile_class_kb[cls];
-                const uint64_t budget = kb < 0 ? (160u * 1024u / (uint32_t)(-kb) - tile_header_bytes) & ~63ull
+                const uint32_t lds_cu = (160u - (uint32_t)e->tile_lds_reserve_kb) * 1024u;
+                const uint64_t budget = kb < 0 ? (lds_cu / (uint32_t)(-kb) - tile_header_bytes) & ~63ull
                                                : std::min<uint64_t>((uint64_t)kb * 1024u, 160u * 1024u - tile_header_bytes);
                 for (uint32_t tw : kTw)
                     for (uint32_t th : kTh) {
@@ -641,6 +647,9 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.sp_blocks = (const SpBlock*)pl->d_sp_blocks.p;
         ca.n_sp_blocks = pl->n_sp_blocks;
         ca.tile_sp_max = (uint32_t)std::min(e->tile_sp_max, (int)TILE_SP_MAX_WINDOWS);
+        ca.tile_finish = (uint32_t)e->tile_finish;
+        ca.tile_ws_min = pl->sp_pad != 0u ? (uint32_t)e->tile_ws_min : 0u;   // no stump-parallel tables: wave-split to the end
+        ca.tile_ws_max = (uint32_t)std::min(e->tile_ws_max, (int)TILE_WS_MAX_WINDOWS);
         int launches = 0;
         std::vector<vj_launch> linfo;
         // every launch is bracketed by its own pair of events on the stream it runs on
@@ -698,6 +707,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             }
             HIP_TRY(hipEventRecord(e->pass_ev[0], e->stream));
             // chain A: tile launches
+            auto chain_a = [&]() -> int {
             for (uint32_t cls = 0; cls < TILE_CLASSES && !hrc && ca.n_tile_units > 0; ++cls) {
                 const uint32_t n_cls = pl->class_first[cls + 1] - pl->class_first[cls];
                 if (!n_cls) continue;
@@ -705,6 +715,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 ta.tile_units = (const UnitDev*)pl->d_tile_units.p + pl->class_first[cls];
                 ta.n_tile_units = n_cls;
                 ta.tile_lds_bytes = pl->class_lds[cls];
+                ta.tile_ticket = d_qcount[0] + (MAX_SCALES - 1 - cls);   // queue 0 does not exist: its counters are free
                 // workgroups per CU: what the LDS allows (160 KiB per CU), at most 4 x 8 waves
                 const int per_cu = std::max(1, std::min(32 / TILE_WAVES, (int)(160u * 1024u / ta.tile_lds_bytes)));
                 const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
@@ -713,20 +724,37 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 hrc = launch_cascade_tile_pass(ta, pl->trees, count, std::max(1, tb), e->stream);
                 if ((rc = end_launch(e->stream))) return rc;
             }
-            // chain B: grid pass, then the queue passes fed by it alone
+                return VJ_OK;
+            };
+            // chain B: grid pass, then the queue passes fed by it alone.  When the chains overlap it goes
+            // first, with one small workgroup per CU (the texture-address unit it is bound by saturates at
+            // one wave per SIMD), so that the tile workgroups find their LDS share next to it.
+            const int b_blocks = two_streams ? std::max(1, e->n_cu * e->concurrent_blocks_per_cu) : n_blocks;
+            auto chain_b = [&]() -> int {
             if (!hrc && ca.n_units > 0) {
                 CascadeArgs ga = queue_args(0);
+                ga.total_waves = (uint32_t)b_blocks * WAVES_PER_BLOCK;
                 if ((rc = begin_launch(VJ_LAUNCH_GRID, 0, ga.stage_begin, ga.stage_end, 0, sB))) return rc;
-                hrc = launch_cascade_pass(ga, true, pl->trees, n_pass == 1, count, pl->general, n_blocks, sB);
+                hrc = launch_cascade_pass(ga, true, pl->trees, n_pass == 1, count, pl->general, b_blocks, sB);
                 if ((rc = end_launch(sB))) return rc;
                 for (size_t ps = 1; ps < first_joint_pass && !hrc; ++ps) {
                     CascadeArgs qa = queue_args(ps);
+                    qa.total_waves = (uint32_t)b_blocks * WAVES_PER_BLOCK;
                     if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, sB))) return rc;
-                    hrc = launch_cascade_pass(qa, false, pl->trees, ps + 1 == n_pass, count, false, n_blocks, sB);
+                    hrc = launch_cascade_pass(qa, false, pl->trees, ps + 1 == n_pass, count, false, b_blocks, sB);
                     if ((rc = end_launch(sB))) return rc;
                 }
             } else {
                 first_joint_pass = 1;
+            }
+                return VJ_OK;
+            };
+            if (two_streams) {
+                if ((rc = chain_b())) return rc;
+                if ((rc = chain_a())) return rc;
+            } else {
+                if ((rc = chain_a())) return rc;
+                if ((rc = chain_b())) return rc;
             }
             if (two_streams) {
                 HIP_TRY(hipEventRecord(e->join_ev, e->stream2));
@@ -946,6 +974,18 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         drop_plans(e);
         return VJ_OK;
     }
+    if (strcmp(key, "tile_finish") == 0) {
+        e->tile_finish = atoi(value) != 0 ? 1 : 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_ws_min") == 0) {
+        e->tile_ws_min = std::max(0, std::min(atoi(value), (int)TILE_SP_MAX_WINDOWS));
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_ws_max") == 0) {
+        e->tile_ws_max = std::max(0, std::min(atoi(value), (int)TILE_WS_MAX_WINDOWS));
+        return VJ_OK;
+    }
     if (strcmp(key, "tile_sp_max") == 0) {
         e->tile_sp_max = std::max(0, std::min(atoi(value), (int)TILE_SP_MAX_WINDOWS));
         return VJ_OK;
@@ -991,6 +1031,16 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         HIP_TRY(hipStreamSynchronize(e->stream));
         e->det_cap_init = (uint32_t)v;
         e->det_cap = 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "concurrent_blocks_per_cu") == 0) {
+        e->concurrent_blocks_per_cu = std::max(1, atoi(value));
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_lds_reserve_kb") == 0) {
+        e->tile_lds_reserve_kb = std::max(0, std::min(atoi(value), 96));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
         return VJ_OK;
     }
     if (strcmp(key, "concurrent") == 0) {  // 1: tile launches and the global first pass overlap on two streams

@@ -334,6 +334,68 @@ __device__ __forceinline__ float stage_sum_stumps(const Img& img, kptr<NodeRecDe
     return stage_sum;
 }
 
+// The same stage on NC chunks of 64 windows at once (lane l holds window l of every chunk): the
+// record fetch, its wait and the scalar corner arithmetic are paid once per stump instead of once per
+// chunk, and the NC independent gather groups overlap each other's LDS latency.  Per window the
+// operations and their order are exactly those of stage_sum_stumps.
+template <int NC, typename Img>
+__device__ __forceinline__ void stage_sum_stumps_multi(const Img& img, kptr<NodeRecDev> tab, uint32_t n_nodes,
+                                                       const uint32_t (&off)[NC], const float (&var)[NC],
+                                                       float (&stage_sum)[NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) stage_sum[c] = 0.0f;
+    NodeRecDev r = tab[0];
+    for (uint32_t j = 0; j < n_nodes; ++j) {
+        const NodeRecDev rn = tab[j + 1 < n_nodes ? j + 1 : j];
+        const float thr = __uint_as_float(r[11]), left = __uint_as_float(r[12]), right = __uint_as_float(r[13]);
+        // node_rect_sum, rectangle-major across the chunks so that all 8*NC gathers of the first two
+        // rectangles are in flight together (the uniform third-rectangle branch would otherwise cut the
+        // chunks apart)
+        const uint32_t lt0 = r[0], lt1 = r[1], lt2 = r[2];
+        const uint32_t dh0 = r[3], dh1 = r[4], dh2 = r[5];
+        const uint32_t dw0 = (uint32_t)(int32_t)(int16_t)(r[6] & 0xffffu), dw1 = (uint32_t)((int32_t)r[6] >> 16),
+                       dw2 = (uint32_t)(int32_t)(int16_t)(r[7] & 0xffffu);
+        const float w0 = __uint_as_float(r[8]), w1 = __uint_as_float(r[9]), w2 = __uint_as_float(r[10]);
+        uint32_t c0[NC][4], c1[NC][4];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            c0[c][0] = img.ld(off[c], lt0);
+            c0[c][1] = img.ld(off[c], lt0 + dw0);
+            c0[c][2] = img.ld(off[c], lt0 + dh0);
+            c0[c][3] = img.ld(off[c], lt0 + dh0 + dw0);
+            c1[c][0] = img.ld(off[c], lt1);
+            c1[c][1] = img.ld(off[c], lt1 + dw1);
+            c1[c][2] = img.ld(off[c], lt1 + dh1);
+            c1[c][3] = img.ld(off[c], lt1 + dh1 + dw1);
+        }
+        float rect_sum[NC];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            const uint32_t r0 = c0[c][0] - c0[c][1] - c0[c][2] + c0[c][3];
+            const uint32_t r1 = c1[c][0] - c1[c][1] - c1[c][2] + c1[c][3];
+            rect_sum[c] = (float)r0 * w0;
+            rect_sum[c] += (float)r1 * w1;
+        }
+        if (w2 != 0.0f) {  // uniform branch (clod.cl:70)
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                c0[c][0] = img.ld(off[c], lt2);
+                c0[c][1] = img.ld(off[c], lt2 + dw2);
+                c0[c][2] = img.ld(off[c], lt2 + dh2);
+                c0[c][3] = img.ld(off[c], lt2 + dh2 + dw2);
+            }
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const uint32_t r2 = c0[c][0] - c0[c][1] - c0[c][2] + c0[c][3];
+                rect_sum[c] += (float)r2 * w2;
+            }
+        }
+#pragma unroll
+        for (int c = 0; c < NC; ++c) stage_sum[c] += (rect_sum[c] >= thr * var[c]) ? right : left;
+        r = rn;
+    }
+}
+
 // Multi-node trees: icvEvalHidHaarClassifier's walk (tempcv.cpp:771-792) on the clod
 // f32 arithmetic.  Nodes of a tree are stored consecutively and a child always has a
 // larger index than its parent, so a tree is evaluated by visiting its records in
@@ -384,7 +446,7 @@ __device__ __forceinline__ float stage_sum_of(const Img& img, kptr<NodeRecDev> t
 // over the wave's LDS queue q[0..n) (all entries belong to one scale and sit at the same
 // stage — linear cascades), compacting survivors in place after every stage.  Returns
 // the number of survivors left at q[0..).
-template <bool TREES, bool COUNT, typename Img>
+template <bool TREES, bool COUNT, bool MULTI = false, typename Img>
 __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img& img, kptr<NodeRecDev> table,
                                                  QEntry* q, uint32_t n, uint32_t lane, uint32_t begin, uint32_t end) {
     kptr<StageDev> stages = as_k(a.stages);
@@ -395,7 +457,37 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
         if (COUNT && lane == 0) atomicAdd(a.stage_entered + s, (unsigned long long)n);
         kptr<NodeRecDev> tab = table + first_node;
         uint32_t m = 0;
-        for (uint32_t base = 0; base < n; base += 64u) {
+        uint32_t base = 0;
+        if (!TREES && MULTI) {
+            // groups of 4, then 2 full-or-partial chunks; a last single chunk falls through to the loop below
+            auto group = [&](auto nc_tag) {
+                constexpr int NC = decltype(nc_tag)::value;
+                QEntry e[NC];
+                uint32_t off[NC];
+                float var[NC], sum[NC];
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const uint32_t i = base + (uint32_t)c * 64u + lane;
+                    e[c] = q[i < n ? i : 0u];
+                    off[c] = e[c].off;
+                    var[c] = e[c].var;
+                }
+                stage_sum_stumps_multi<NC>(img, tab, n_nodes, off, var, sum);
+                __builtin_amdgcn_wave_barrier();   // every entry of the group is in registers
+#pragma unroll
+                for (int c = 0; c < NC; ++c) {
+                    const bool pass = base + (uint32_t)c * 64u + lane < n && sum[c] >= threshold;
+                    const unsigned long long mask = __ballot(pass);
+                    if (pass) q[m + mbcnt(mask)] = e[c];
+                    m += (uint32_t)__popcll(mask);
+                }
+                __builtin_amdgcn_wave_barrier();
+                base += (uint32_t)NC * 64u;
+            };
+            while (base + 192u < n) group(std::integral_constant<int, 4>{});
+            if (base + 64u < n) group(std::integral_constant<int, 2>{});
+        }
+        for (; base < n; base += 64u) {
             const uint32_t i = base + lane;
             const bool act = i < n;
             const QEntry e = q[act ? i : 0u];
@@ -594,7 +686,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
 // clod.cl:81) — exactly the sequence of f32 additions a single lane would have made — compares with the
 // stage threshold, and the survivors are compacted across the waves.  Replaces the serial tail (one thin
 // wave, ~300 cycles per stump) of the late stages.
-template <bool COUNT>
+template <bool COUNT, bool STAMPS = true>
 __device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, const LdsImg& img,
                                                         const uint32_t* table /* the scale's tile table, global */,
                                                         QEntry* lds_q, unsigned long long* lds_mask, uint32_t* lds_sp,
@@ -602,8 +694,8 @@ __device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, co
                                                         uint32_t n_stages, uint32_t lane, uint32_t wib,
                                                         unsigned long long& t_last) {
     unsigned long long sp_acc[5] = {0, 0, 0, 0, 0};
-#define SPSTAMP(ph) do { if (VJ_STAMPS && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sp_acc[ph] += t_ - t_last; t_last = t_; } } while (0)
-#define SPFLUSH() do { if (VJ_STAMPS && threadIdx.x == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(a.stage_entered + 54 + i_, sp_acc[i_]); } } while (0)
+#define SPSTAMP(ph) do { if (VJ_STAMPS && STAMPS && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sp_acc[ph] += t_ - t_last; t_last = t_; } } while (0)
+#define SPFLUSH() do { if (VJ_STAMPS && STAMPS && threadIdx.x == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(a.stage_entered + 54 + i_, sp_acc[i_]); } } while (0)
     kptr<StageDev> stages = as_k(a.stages);
     kptr<uint32_t> blocks = as_k(reinterpret_cast<const uint32_t*>(a.sp_blocks));   // {first_node, desc} pairs
     const uint32_t tid = wib * 64u + lane;
@@ -766,6 +858,179 @@ __device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, co
     }
 }
 
+// Two consecutive stumps on one window with every gather of both in flight together.  The third
+// rectangles are read for both when either stump has one (an absent rectangle has lt = dh = dw = 0:
+// four reads of the window's own origin, harmless) but only added where the weight is non-zero, as
+// in node_rect_sum.
+template <typename Img>
+__device__ __forceinline__ void node_rect_sum_pair(const Img& img, const NodeRecDev& ra, const NodeRecDev& rb, uint32_t off,
+                                                   float& sum_a, float& sum_b) {
+    uint32_t v[2][3][4];
+    const NodeRecDev* rr[2] = {&ra, &rb};
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const NodeRecDev& r = *rr[p];
+        const uint32_t dw0 = (uint32_t)(int32_t)(int16_t)(r[6] & 0xffffu), dw1 = (uint32_t)((int32_t)r[6] >> 16);
+        v[p][0][0] = img.ld(off, r[0]);
+        v[p][0][1] = img.ld(off, r[0] + dw0);
+        v[p][0][2] = img.ld(off, r[0] + r[3]);
+        v[p][0][3] = img.ld(off, r[0] + r[3] + dw0);
+        v[p][1][0] = img.ld(off, r[1]);
+        v[p][1][1] = img.ld(off, r[1] + dw1);
+        v[p][1][2] = img.ld(off, r[1] + r[4]);
+        v[p][1][3] = img.ld(off, r[1] + r[4] + dw1);
+    }
+    float out[2];
+#pragma unroll
+    for (int p = 0; p < 2; ++p) {
+        const NodeRecDev& r = *rr[p];
+        const uint32_t r0 = v[p][0][0] - v[p][0][1] - v[p][0][2] + v[p][0][3];
+        const uint32_t r1 = v[p][1][0] - v[p][1][1] - v[p][1][2] + v[p][1][3];
+        out[p] = (float)r0 * __uint_as_float(r[8]);
+        out[p] += (float)r1 * __uint_as_float(r[9]);
+    }
+    const float wa2 = __uint_as_float(ra[10]), wb2 = __uint_as_float(rb[10]);
+    if (wa2 != 0.0f || wb2 != 0.0f) {   // uniform
+#pragma unroll
+        for (int p = 0; p < 2; ++p) {
+            const NodeRecDev& r = *rr[p];
+            const uint32_t dw2 = (uint32_t)(int32_t)(int16_t)(r[7] & 0xffffu);
+            v[p][2][0] = img.ld(off, r[2]);
+            v[p][2][1] = img.ld(off, r[2] + dw2);
+            v[p][2][2] = img.ld(off, r[2] + r[5]);
+            v[p][2][3] = img.ld(off, r[2] + r[5] + dw2);
+        }
+        if (wa2 != 0.0f) out[0] += (float)(v[0][2][0] - v[0][2][1] - v[0][2][2] + v[0][2][3]) * wa2;
+        if (wb2 != 0.0f) out[1] += (float)(v[1][2][0] - v[1][2][1] - v[1][2][2] + v[1][2][3]) * wb2;
+    }
+    sum_a = out[0];
+    sum_b = out[1];
+}
+
+// Wave-split finish of a tile (stump cascades).  T <= TILE_WS_MAX_WINDOWS packed survivors sit in
+// lds_q[0, T): c = ceil(T / 64) chunks.  Thin tiles are latency-bound when one wave walks a whole
+// stage for its chunk while the others idle, so the stage's stumps are split into K = 8 / c
+// contiguous ranges and wave w evaluates range w / c on chunk w % c, one window per lane, records
+// through the scalar cache as in the dense sweep.  Each wave leaves, per window, the f32 sum of its
+// range (added in stump order from 0) and one verdict bit per stump.  The stage decision adds the
+// K range sums: that is the stage's leaf values in a different association than the reference's
+// single running sum, so it is only trusted when it clears the threshold by more than sp_delta (the
+// host's a-priori bound on the difference between ANY two summation orders of the stage); windows
+// inside the band replay their verdict bits in stump order — the reference's exact sequence of f32
+// additions (clod.cl:81).  K = 1 is the plain sequential sum.  Results are bit-identical either way.
+template <bool COUNT>
+__device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const LdsImg& img, kptr<NodeRecDev> table,
+                                                    QEntry* lds_q, uint32_t* lds_cnt, uint32_t T, uint32_t& st_io,
+                                                    uint32_t n_stages, uint32_t lane, uint32_t wib,
+                                                    unsigned long long& t_last) {
+    unsigned long long sp_acc[5] = {0, 0, 0, 0, 0};
+    constexpr bool STAMPS = true;
+    kptr<StageDev> stages = as_k(a.stages);
+    // scratch behind the packed entries: per producing wave 64 range sums + 4 x 64 verdict words
+    uint32_t* lds_x = reinterpret_cast<uint32_t*>(lds_q + TILE_WS_MAX_WINDOWS);
+    uint32_t s = st_io;
+    // below tile_ws_min windows a chunk's lanes are mostly empty: the caller continues stump-parallel
+    for (; s < n_stages && T != 0u && T >= a.tile_ws_min; ++s) {
+        if (COUNT && threadIdx.x == 0) atomicAdd(a.stage_entered + s, (unsigned long long)T);
+        const uint32_t n = stages[s].n_nodes;
+        const float thr_s = stages[s].threshold, delta = stages[s].sp_delta;
+        kptr<NodeRecDev> tab = table + stages[s].first_node;
+        const uint32_t c = (T + 63u) >> 6;
+        uint32_t K = (uint32_t)TILE_WAVES / c;
+        uint32_t rs = (n + K - 1u) / K;
+        rs = (rs + 1u) & ~1u;                      // even: pairs never straddle two ranges
+        if (rs > 128u || K == 1u) { K = 1u; rs = n; }
+        const uint32_t chunk = wib % c, range = wib / c;   // uniform
+        const uint32_t i = chunk * 64u + lane;
+        const bool valid = i < T;
+        const QEntry e = lds_q[valid ? i : 0u];
+        bool pass = false;
+        if (range < K) {
+            if (K == 1u) {
+                pass = valid && stage_sum_stumps(img, tab, n, e.off, e.var) >= thr_s;
+            } else {
+                const uint32_t j0 = min(range * rs, n), j1 = min(j0 + rs, n);
+                float psum = 0.0f;
+                uint32_t* xw = lds_x + wib * 320u;   // [0,64) sums, [64 + 64 w, ...) verdict word w
+                for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += 32u, ++wd) {
+                    const uint32_t m = min(32u, j1 - w0);
+                    uint32_t bw = 0u;
+                    uint32_t k = 0;
+                    NodeRecDev ra = tab[w0], rb = tab[min(w0 + 1u, j1 - 1u)];
+                    for (; k + 1u < m; k += 2u) {
+                        // the next pair's records travel while this pair is evaluated
+                        const NodeRecDev na = tab[min(w0 + k + 2u, j1 - 1u)], nb = tab[min(w0 + k + 3u, j1 - 1u)];
+                        float sa, sb;
+                        node_rect_sum_pair(img, ra, rb, e.off, sa, sb);
+                        const bool pa = sa >= __uint_as_float(ra[11]) * e.var, pb = sb >= __uint_as_float(rb[11]) * e.var;
+                        psum += pa ? __uint_as_float(ra[13]) : __uint_as_float(ra[12]);
+                        psum += pb ? __uint_as_float(rb[13]) : __uint_as_float(rb[12]);
+                        bw |= (pa ? 1u : 0u) << k;
+                        bw |= (pb ? 2u : 0u) << k;
+                        ra = na;
+                        rb = nb;
+                    }
+                    if (k < m) {   // odd tail (only the last word of the stage's last range)
+                        const bool pa = node_rect_sum(img, ra, e.off) >= __uint_as_float(ra[11]) * e.var;
+                        psum += pa ? __uint_as_float(ra[13]) : __uint_as_float(ra[12]);
+                        bw |= (pa ? 1u : 0u) << k;
+                    }
+                    xw[64u + wd * 64u + lane] = bw;
+                }
+                xw[lane] = __float_as_uint(psum);
+            }
+        }
+        SPSTAMP(0);
+        if (K > 1u) {
+            lds_barrier();   // every range sum and verdict word of the stage is in LDS
+            SPSTAMP(1);
+            if (wib < c) {   // range 0's wave decides its chunk
+                float approx = 0.0f;
+                for (uint32_t r = 0; r < K; ++r) approx += __uint_as_float(lds_x[(r * c + wib) * 320u + lane]);
+                const float d = approx - thr_s;
+                const bool clear = d > delta || d < -delta;
+                pass = valid && d > delta;
+                if (__ballot(valid && !clear) != 0ull) {
+                    // replay in stump order; the leaf values come through the scalar cache
+                    float sum = 0.0f;
+                    for (uint32_t r = 0; r < K; ++r) {
+                        const uint32_t j0 = min(r * rs, n), j1 = min(j0 + rs, n);
+                        const uint32_t* xw = lds_x + (r * c + wib) * 320u + 64u;
+                        for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += 32u, ++wd) {
+                            const uint32_t m = min(32u, j1 - w0);
+                            const uint32_t bw = xw[wd * 64u + lane];
+                            kptr<uint32_t> lr = reinterpret_cast<kptr<uint32_t>>(tab + w0);
+                            for (uint32_t k = 0; k < m; ++k)
+                                sum += (bw >> k) & 1u ? __uint_as_float(lr[k * 16u + 13u]) : __uint_as_float(lr[k * 16u + 12u]);
+                        }
+                    }
+                    if (!clear) pass = valid && sum >= thr_s;
+                }
+            }
+        }
+        SPSTAMP(2);
+        // survivors: compact lds_q across the deciding waves
+        const unsigned long long mask = __ballot(pass);
+        if (lane == 0) lds_cnt[1u + wib] = (uint32_t)__popcll(mask);
+        lds_barrier();   // every entry is in registers, every wave's count is published
+        SPSTAMP(3);
+        uint32_t before = 0, total = 0;
+#pragma unroll
+        for (uint32_t w = 0; w < TILE_WAVES; ++w) {
+            const uint32_t cw = lds_cnt[1u + w];
+            before += w < wib ? cw : 0u;
+            total += cw;
+        }
+        if (pass) lds_q[before + mbcnt(mask)] = e;
+        T = __builtin_amdgcn_readfirstlane(total);
+        lds_barrier();   // lds_q is repacked; lds_cnt and the scratch may be rewritten
+        SPSTAMP(4);
+    }
+    SPFLUSH();
+    st_io = s;
+    return T;
+}
+
 template <bool TREES, bool COUNT>
 __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
@@ -783,7 +1048,13 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
 
 #define STAMP(ph) do { if (VJ_STAMPS && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(a.stage_entered + 40 + (ph), t_ - t_last); t_last = t_; } } while (0)
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
-    for (uint32_t u = blockIdx.x; u < total_units; u += gridDim.x) {
+    // Tiles are handed out dynamically (first one = blockIdx.x, then tickets from a global counter): a
+    // workgroup that becomes resident late — e.g. because another kernel holds part of the CU — simply
+    // finds fewer tickets left.  The ticket for the next tile is drawn while this one is processed.
+    uint32_t u = blockIdx.x;
+    while (u < total_units) {
+        uint32_t next_u = 0;
+        if (threadIdx.x == 0) next_u = gridDim.x + atomicAdd(a.tile_ticket, 1u);
         const uint32_t frame = u / a.n_tile_units;
         const uint32_t r = u - frame * a.n_tile_units;
         const uint32_t slot = units[r].scale;
@@ -930,9 +1201,25 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                 q = lds_q + first;
                 n = min(share, total - first);
                 STAMP(3 + min(st, 8u));   // time of stage st-1 (incl. waiting for the slowest wave) + this re-pack
-                if (!TREES && st >= a.tile_sp_begin && total != 0u && total <= a.tile_sp_max) {
+                if (!TREES && a.tile_finish == 1u && st >= a.tile_sp_begin && total != 0u && total <= a.tile_ws_max) {
+                    // few windows left: finish the whole cascade with the stage's stumps split over the waves
+                    uint32_t s_next = st;
+                    uint32_t left = tile_wave_split<COUNT>(a, img, table, lds_q, lds_cnt, total, s_next, n_stages_total, lane,
+                                                           wib, t_last);
+                    if (left != 0u && s_next < n_stages_total)
+                        left = tile_stump_parallel<COUNT, false>(
+                            a, img, a.table + (size_t)scales[slot].tile_table_first * 16u, lds_q,
+                            reinterpret_cast<unsigned long long*>(lds_q + TILE_SP_MAX_WINDOWS), lds_tab, lds_cnt, left, s_next,
+                            n_stages_total, lane, wib, t_last);
+                    q = lds_q;
+                    n = wib == 0u ? left : 0u;
+                    dest = a.n_pass;
+                    STAMP(12);
+                    break;
+                }
+                if (!TREES && a.tile_finish == 0u && st >= a.tile_sp_begin && total != 0u && total <= a.tile_sp_max) {
                     // few windows left: finish the whole cascade stump-parallel; survivors are detections
-                    const uint32_t left = tile_stump_parallel<COUNT>(
+                    const uint32_t left = tile_stump_parallel<COUNT, true>(
                         a, img, a.table + (size_t)scales[slot].tile_table_first * 16u, lds_q,
                         reinterpret_cast<unsigned long long*>(lds_q + TILE_SP_MAX_WINDOWS), lds_tab, lds_cnt, total, st,
                         n_stages_total, lane, wib, t_last);
@@ -950,7 +1237,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                     ++next_p;
                 }
             }
-            if (n != 0u) n = sweep_stages<TREES, COUNT>(a, img, table, q, n, lane, st, st + 1u);
+            if (n != 0u) n = sweep_stages<TREES, COUNT, true>(a, img, table, q, n, lane, st, st + 1u);
         }
         if (n != 0u) {
             // survivors: tile-local offset -> global byte offset in the batch sum image
@@ -975,7 +1262,10 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
             }
         }
         STAMP(13);
-        __builtin_amdgcn_wave_barrier();
+        __syncthreads();   // the tile is finished: lds_cnt may carry the next ticket
+        if (threadIdx.x == 0) lds_cnt[TILE_WAVES + 8] = next_u;
+        __syncthreads();
+        u = __builtin_amdgcn_readfirstlane(lds_cnt[TILE_WAVES + 8]);
     }
 }
 

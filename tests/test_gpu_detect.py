@@ -125,6 +125,8 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
             env.configure("tile_repack", {3: "", 10: "3,5", 22: "1,2,3,4,5,6,7,9,11,13,17", 14: "2", 7: "6"}[tile_end])
             env.configure("tile_sp_begin", {3: 64, 10: 8, 22: 4, 14: 1, 7: 6}[tile_end])
             env.configure("tile_sp_max", {3: 96, 10: 48, 22: 256, 14: 200, 7: 45}[tile_end])
+            env.configure("tile_finish", {3: 1, 10: 1, 22: 0, 14: 1, 7: 0}[tile_end])
+            env.configure("tile_ws_max", {3: 512, 10: 100, 22: 512, 14: 512, 7: 64}[tile_end])
             for split in ("", "22", "7", "2,4,6,9,12,15,18"):
                 env.configure("pass_split", split)
                 r = env.detect(c, frames, p)
@@ -139,6 +141,36 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("tile_min_lanes", 0)
         env.configure("tile_repack", ",".join(str(i) for i in range(2, 22)))
         env.configure("tile_sp_begin", 3)
+        env.configure("tile_sp_max", 192)
+        env.configure("tile_finish", 1)
+        env.configure("tile_ws_max", 512)
+
+
+def test_finish_variants_agree(env, cascades):
+    """The stump-parallel and the wave-split finish of the tile kernel (and neither) give the same rectangles and
+    per-stage counts as the oracle-checked default, on frames that keep many windows alive (noise) and few (smooth)."""
+    c, _ = cascades("frontalface_alt")
+    frames = np.stack([make_frame("noise", 31, 540, 960), make_frame("smooth", 32, 540, 960),
+                       make_frame("blocks", 33, 540, 960)])
+    p = default_params(flags=VJ_FLAG_COUNTERS)
+    try:
+        env.configure("tile_sp_begin", 99)
+        base = env.detect(c, frames, p)
+        for finish, begin, ws_max, sp_max, ws_min in ((1, 3, 512, 192, 32), (1, 1, 512, 192, 0), (1, 2, 200, 192, 100),
+                                                      (1, 5, 64, 192, 8), (1, 3, 512, 192, 256), (0, 3, 512, 192, 32),
+                                                      (0, 4, 512, 256, 32)):
+            env.configure("tile_finish", finish)
+            env.configure("tile_ws_min", ws_min)
+            env.configure("tile_sp_begin", begin)
+            env.configure("tile_ws_max", ws_max)
+            env.configure("tile_sp_max", sp_max)
+            r = env.detect(c, frames, p)
+            assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, (finish, begin, ws_max)
+    finally:
+        env.configure("tile_finish", 1)
+        env.configure("tile_sp_begin", 3)
+        env.configure("tile_ws_max", 512)
+        env.configure("tile_ws_min", 32)
         env.configure("tile_sp_max", 192)
 
 

@@ -123,3 +123,101 @@ if "split" in what:
         r = run(default_params())
         print(f"split {sp}: cascade {r.cascade_ms:.2f} ms passes {[round(x[2],2) for x in r.passes]}", flush=True)
     env.configure("pass_split", "")
+if "dense" in what:
+    # cost of the dense part of the tile kernel: cut the first pass after k stages, no stump-parallel finish
+    env.configure("tile_sp_begin", 99)
+    for k in (1, 2, 3, 4, 5):
+        env.configure("pass_split", str(k)); env.configure("tile_end", k)
+        pc = default_params(flags=VJ_FLAG_COUNTERS)
+        rc = run(pc, 1)
+        ev = sum(rc.stage_entered[s] * c.stages[s]["n_trees"] for s in range(k))
+        r = run(default_params())
+        tl = [l for l in r.launches if l["kind"] == "tile"]
+        print(f"k={k}: tile launches {[round(l['ms'],2) for l in tl]} all {[ (l['kind'], round(l['ms'],2)) for l in r.launches]} entered {rc.stage_entered[:k+1]} evals[0,k)={ev/1e9:.2f}G", flush=True)
+    env.configure("tile_sp_begin", 3); env.configure("pass_split", ""); env.configure("tile_end", 12)
+if "ws" in what:
+    env.configure("tile_finish", 1)
+    for begin in (2, 3, 4):
+        for wsmax in (128, 256, 384, 512):
+            env.configure("tile_sp_begin", begin); env.configure("tile_ws_max", wsmax)
+            r = run(default_params())
+            print(f"ws begin={begin} max={wsmax}: cascade {r.cascade_ms:.2f} ms launches {[(l['kind'], round(l['ms'],2)) for l in r.launches]}", flush=True)
+    env.configure("tile_finish", 0); env.configure("tile_sp_begin", 3)
+    r = run(default_params())
+    print(f"sp: cascade {r.cascade_ms:.2f} ms launches {[(l['kind'], round(l['ms'],2)) for l in r.launches]}", flush=True)
+    env.configure("tile_finish", 1); env.configure("tile_ws_max", 512)
+if "wsmin" in what:
+    env.configure("tile_finish", 1); env.configure("tile_sp_begin", 3); env.configure("tile_ws_max", 512)
+    for wsmin in (0, 8, 16, 24, 32, 48, 64, 96, 128, 256):
+        env.configure("tile_ws_min", wsmin)
+        r = run(default_params())
+        print(f"ws_min={wsmin}: cascade {r.cascade_ms:.2f} ms launches {[(l['kind'], round(l['ms'],2)) for l in r.launches]}", flush=True)
+    env.configure("tile_ws_min", 32)
+if "large2" in what:
+    env.configure("tile_finish", 1); env.configure("tile_ws_max", 512); env.configure("tile_ws_min", 48)
+    env.configure("tile_repack", ",".join(str(i) for i in range(1, 22)))
+    for begin in (1, 2):
+        env.configure("tile_sp_begin", begin)
+        for acc, mdw in ((256, 600), (128, 1200), (64, 1200), (64, 2500), (64, 5000)):
+            env.configure("tile_accept_windows", acc); env.configure("tile_max_dwords_per_window", mdw)
+            r = run(default_params(), 2)
+            print(f"begin={begin} accept={acc} max_dw/win={mdw}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("tile_accept_windows", 256); env.configure("tile_max_dwords_per_window", 600); env.configure("tile_sp_begin", 3)
+    env.configure("tile_repack", ",".join(str(i) for i in range(2, 22)))
+if "conc2" in what:
+    env.configure("tile_finish", 1); env.configure("tile_ws_max", 512); env.configure("tile_ws_min", 48)
+    def show(tag):
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(c, df, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        print(f"{tag}: wall {wall:.2f} ms cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.detect(c, df, default_params())
+    show("serial")
+    for reserve in (0, 20, 36):
+        env.configure("tile_lds_reserve_kb", reserve)
+        env.configure("concurrent", 0); env.detect(c, df, default_params()); show(f"serial reserve={reserve}")
+        for bpc in (1, 2):
+            env.configure("concurrent", 1); env.configure("concurrent_blocks_per_cu", bpc)
+            env.detect(c, df, default_params())
+            show(f"concurrent reserve={reserve} bpc={bpc}")
+    env.configure("concurrent", 0); env.configure("tile_lds_reserve_kb", 0)
+if "conc3" in what:
+    env.configure("tile_finish", 1); env.configure("tile_ws_max", 512); env.configure("tile_ws_min", 48)
+    base = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+    def show(tag):
+        env.detect(c, df, default_params())
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(c, df, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        rc = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+        ok = np.array_equal(rc.rects, base.rects) and rc.stage_entered == base.stage_entered
+        print(f"{tag}: same={ok} wall {wall:.2f} ms cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{l['ms']:.1f}" for l in r.launches), flush=True)
+    for bpc in (8, 4, 2, 1):
+        env.configure("blocks_per_cu", bpc); show(f"serial blocks_per_cu={bpc}")
+    env.configure("blocks_per_cu", 8)
+    for reserve in (0, 8, 20):
+        env.configure("tile_lds_reserve_kb", reserve)
+        for bpc in (1,):
+            env.configure("concurrent", 1); env.configure("concurrent_blocks_per_cu", bpc)
+            show(f"concurrent reserve={reserve} bpc={bpc}")
+        env.configure("concurrent", 0)
+    env.configure("tile_lds_reserve_kb", 0)
+if "conc4" in what:
+    env.configure("tile_finish", 1); env.configure("tile_ws_max", 512); env.configure("tile_ws_min", 48)
+    base = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+    def show(tag):
+        env.detect(c, df, default_params())
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(c, df, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        rc = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+        ok = np.array_equal(rc.rects, base.rects) and rc.stage_entered == base.stage_entered
+        print(f"{tag}: same={ok} wall {wall:.2f} ms cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("concurrent", 1); env.configure("concurrent_blocks_per_cu", 1)
+    for reserve in (18, 20, 24):
+        env.configure("tile_lds_reserve_kb", reserve)
+        for mdw in (600, 400, 300, 200, 150):
+            env.configure("tile_max_dwords_per_window", mdw)
+            show(f"concurrent reserve={reserve} mdw={mdw}")
+    env.configure("tile_max_dwords_per_window", 600)
+    env.configure("concurrent", 0); env.configure("tile_lds_reserve_kb", 0)
