@@ -95,9 +95,9 @@ struct vj_env {
     hipStream_t stream2 = nullptr;   // second chain of the first part of the cascade
     int max_subbatch = 0;      // > 0: cap on frames per sub-batch (tests)
     uint32_t det_cap_init = 1u << 16;  // initial capacity of the detection buffer (grows on overflow)
-    int concurrent = 0;   // 1: the tile chain and the global-gather chain overlap on two streams
+    int concurrent = 1;   // 1: the tile chain and the global-gather chain overlap on two streams
     int concurrent_blocks_per_cu = 1;   // workgroups per CU of the global-gather chain while it overlaps
-    int tile_lds_reserve_kb = 0;        // LDS per CU the tile classes leave to the other chain
+    int tile_lds_reserve_kb = 18;       // LDS per CU the tile classes leave to the other chain
     char name[256] = "";
     int n_cu = 0;
     // image buffers
@@ -117,7 +117,7 @@ struct vj_env {
                                                      // workgroups share a CU's 160 KiB; all 0 disables the tile path
     int tile_min_windows = 768;   // a class is acceptable for a scale when a tile holds at least this many windows
     int tile_max_dwords_per_window = 600;  // staging a tile must stay far cheaper than gathering its windows from L2
-    int tile_accept_windows = 256;  // scales whose best tile holds fewer windows stay on the global-gather path
+    int tile_accept_windows = 768;  // scales whose best tile holds fewer windows stay on the global-gather path
     int tile_end = 12;            // tile launches never enter a pass that begins at or beyond this stage
     int tile_min_lanes = 0;       // a tile leaves at a pass boundary when fewer windows than this survive in it
     unsigned long long tile_repack_mask = 0x3ffffcull;  // stages (2..21) before which a tile re-packs its survivors
@@ -125,7 +125,7 @@ struct vj_env {
     int tile_sp_max = 192;
     int tile_finish = 1;          // 0: stump-parallel finish, 1: wave-split finish
     int tile_ws_max = 512;
-    int tile_ws_min = 32;         // ... below this many the stump-parallel finish takes over        // windows a tile may carry into the wave-split finish
+    int tile_ws_min = 48;         // ... below this many the stump-parallel finish takes over        // windows a tile may carry into the wave-split finish
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales        // ... once at most this many of its windows survive
     std::vector<int> split_override;
 };

@@ -110,10 +110,13 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         r = env.detect(c, frames, p)
         assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
         env.configure("tile_deinterleave", 1)
+        for conc, reserve in ((0, 18), (0, 0), (1, 0), (1, 40)):
+            env.configure("concurrent", conc)
+            env.configure("tile_lds_reserve_kb", reserve)
+            r = env.detect(c, frames, p)
+            assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, (conc, reserve)
         env.configure("concurrent", 1)
-        r = env.detect(c, frames, p)
-        assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
-        env.configure("concurrent", 0)
+        env.configure("tile_lds_reserve_kb", 18)
         # LDS-tile path off / small / large tiles / shallow / deep: the tile and the
         # global-gather paths agree bit for bit
         for classes, tile_end, minw in (("0,0,0", 10, 1024), ("24,40,60", 3, 1024), ("36,64,140", 10, 1024),
@@ -133,6 +136,8 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
                 assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, \
                     (classes, tile_end, minw, split)
     finally:
+        env.configure("concurrent", 1)
+        env.configure("tile_lds_reserve_kb", 18)
         env.configure("pass_split", "")
         env.configure("blocks_per_cu", 8)
         env.configure("tile_classes_kb", "-2,-1,0")
@@ -170,7 +175,7 @@ def test_finish_variants_agree(env, cascades):
         env.configure("tile_finish", 1)
         env.configure("tile_sp_begin", 3)
         env.configure("tile_ws_max", 512)
-        env.configure("tile_ws_min", 32)
+        env.configure("tile_ws_min", 48)
         env.configure("tile_sp_max", 192)
 
 

@@ -221,3 +221,23 @@ if "conc4" in what:
             show(f"concurrent reserve={reserve} mdw={mdw}")
     env.configure("tile_max_dwords_per_window", 600)
     env.configure("concurrent", 0); env.configure("tile_lds_reserve_kb", 0)
+if "conc5" in what:
+    env.configure("tile_finish", 1); env.configure("tile_ws_max", 512); env.configure("tile_ws_min", 48)
+    base = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+    def show(tag):
+        env.detect(c, df, default_params())
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(c, df, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        rc = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+        ok = np.array_equal(rc.rects, base.rects) and rc.stage_entered == base.stage_entered
+        print(f"{tag}: same={ok} wall {wall:.2f} ms cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("concurrent", 1); env.configure("concurrent_blocks_per_cu", 1)
+    env.configure("tile_lds_reserve_kb", 18)
+    for acc, minw in ((256, 768), (512, 768), (768, 768), (1024, 1024), (1536, 1536), (2048, 2048)):
+        env.configure("tile_accept_windows", acc); env.configure("tile_min_windows", minw)
+        show(f"concurrent reserve=18 accept={acc} minw={minw}")
+    env.configure("tile_accept_windows", 256); env.configure("tile_min_windows", 768)
+    env.configure("tile_lds_reserve_kb", 36); env.configure("concurrent_blocks_per_cu", 2)
+    show("concurrent reserve=36 bpc=2")
+    env.configure("concurrent", 0); env.configure("tile_lds_reserve_kb", 0)
