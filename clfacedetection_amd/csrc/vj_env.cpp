@@ -118,9 +118,9 @@ struct vj_env {
     int tile_min_windows = 768;   // a class is acceptable for a scale when a tile holds at least this many windows
     int tile_max_dwords_per_window = 600;  // staging a tile must stay far cheaper than gathering its windows from L2
     int tile_accept_windows = 768;  // scales whose best tile holds fewer windows stay on the global-gather path
-    int tile_end = 12;            // tile launches never enter a pass that begins at or beyond this stage
+    int tile_end = 64;            // tile launches never enter a pass that begins at or beyond this stage
     int tile_min_lanes = 0;       // a tile leaves at a pass boundary when fewer windows than this survive in it
-    unsigned long long tile_repack_mask = 0x3ffffcull;  // stages (2..21) before which a tile re-packs its survivors
+    unsigned long long tile_repack_mask = ~3ull;  // stages (2 and later) before which a tile re-packs its survivors
     int tile_sp_begin = 3;        // first stage at which a tile may switch to the stump-parallel finish (>= 64: never)
     int tile_sp_max = 192;
     int tile_finish = 1;          // 0: stump-parallel finish, 1: wave-split finish
@@ -157,12 +157,13 @@ static std::vector<uint32_t> default_pass_bounds(const vj_cascade& c, const Stag
         for (int v : override_)
             if (v > (int)b.back() && v < (int)n) b.push_back((uint32_t)v);
     } else {
-        // cut after roughly 110, 250 and 600 cumulative nodes (frontalface_alt: 5 | 8 | 12), measured
-        // best on 1080p batches: [0,5) global first pass, re-packed queue passes after it
-        const uint32_t cuts[3] = {110, 250, 600};
+        // cut after roughly 110 and 250 cumulative nodes (frontalface_alt: 5 | 8), measured best on 1080p
+        // batches: [0,5) global first pass, then two re-packed queue passes, all on the global-gather chain
+        // while the tile chain runs the whole cascade next to it
+        const uint32_t cuts[2] = {110, 250};
         uint32_t acc = 0;
         int ci = 0;
-        for (uint32_t s = 0; s < n && ci < 3; ++s) {
+        for (uint32_t s = 0; s < n && ci < 2; ++s) {
             acc += prog.n_nodes[s];
             if (acc >= cuts[ci] && s + 1 < n) {
                 b.push_back(s + 1);

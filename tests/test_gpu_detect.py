@@ -141,7 +141,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("pass_split", "")
         env.configure("blocks_per_cu", 8)
         env.configure("tile_classes_kb", "-2,-1,0")
-        env.configure("tile_end", 12)
+        env.configure("tile_end", 64)
         env.configure("tile_min_windows", 768)
         env.configure("tile_min_lanes", 0)
         env.configure("tile_repack", ",".join(str(i) for i in range(2, 22)))

@@ -75,7 +75,7 @@ if "sp" in what:
         env.configure("tile_sp_begin", spb); env.configure("tile_sp_max", spm); env.configure("tile_repack", rp_all); env.configure("pass_split", sp); env.configure("tile_end", te)
         r = run(default_params(), 2)
         print(f"sp_begin={spb} sp_max={spm} split={sp!r} tile_end={te}: cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{l['ms']:.1f}" for l in r.launches), flush=True)
-    env.configure("tile_sp_begin", 3); env.configure("tile_sp_max", 192); env.configure("tile_repack", rp_all); env.configure("pass_split", ""); env.configure("tile_end", 12)
+    env.configure("tile_sp_begin", 3); env.configure("tile_sp_max", 192); env.configure("tile_repack", rp_all); env.configure("pass_split", ""); env.configure("tile_end", 64)
 if "large" in what:
     for acc, mdw in ((512, 600), (256, 600), (128, 600), (128, 1200), (64, 1200), (64, 2500), (32, 2500), (16, 5000)):
         env.configure("tile_accept_windows", acc); env.configure("tile_max_dwords_per_window", mdw)
@@ -134,7 +134,7 @@ if "dense" in what:
         r = run(default_params())
         tl = [l for l in r.launches if l["kind"] == "tile"]
         print(f"k={k}: tile launches {[round(l['ms'],2) for l in tl]} all {[ (l['kind'], round(l['ms'],2)) for l in r.launches]} entered {rc.stage_entered[:k+1]} evals[0,k)={ev/1e9:.2f}G", flush=True)
-    env.configure("tile_sp_begin", 3); env.configure("pass_split", ""); env.configure("tile_end", 12)
+    env.configure("tile_sp_begin", 3); env.configure("pass_split", ""); env.configure("tile_end", 64)
 if "ws" in what:
     env.configure("tile_finish", 1)
     for begin in (2, 3, 4):
@@ -241,3 +241,26 @@ if "conc5" in what:
     env.configure("tile_lds_reserve_kb", 36); env.configure("concurrent_blocks_per_cu", 2)
     show("concurrent reserve=36 bpc=2")
     env.configure("concurrent", 0); env.configure("tile_lds_reserve_kb", 0)
+if "conc6" in what:
+    base = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+    def show(tag):
+        env.detect(c, df, default_params())
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(c, df, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        rc = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+        ok = np.array_equal(rc.rects, base.rects) and rc.stage_entered == base.stage_entered
+        print(f"{tag}: same={ok} wall {wall:.2f} ms cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    show("default")
+    for sp in ("3,6,10", "4,8,13", "6,13", "5,13", "5,8,11,14", "4,6,8,13", "5,8"):
+        env.configure("pass_split", sp); show(f"split {sp}")
+    env.configure("pass_split", "")
+    for acc in (900, 1024, 1280):
+        env.configure("tile_accept_windows", acc); show(f"accept {acc}")
+    env.configure("tile_accept_windows", 768)
+    for te in (8, 13, 22):
+        env.configure("tile_end", te); show(f"tile_end {te}")
+    env.configure("tile_end", 64)
+    for wsmin, begin in ((32, 3), (64, 3), (48, 2), (48, 4)):
+        env.configure("tile_ws_min", wsmin); env.configure("tile_sp_begin", begin); show(f"ws_min {wsmin} begin {begin}")
+    env.configure("tile_ws_min", 48); env.configure("tile_sp_begin", 3)
