@@ -44,7 +44,7 @@ def main() -> int:
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cascade", default="frontalface_alt")
-    ap.add_argument("--cpu-frames", type=int, default=4, help="frames of the batch timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the batch timed on the CPU oracle (0 = skip)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -158,7 +158,8 @@ def main() -> int:
             tr = trees[st["first_tree"]:st["first_tree"] + st["n_trees"]]
             rects_per_stage.append(int(sum(int(nodes["n_rects"][t["first_node"]:t["first_node"] + t["n_nodes"]].sum())
                                            for t in tr)))
-        kname = {"tile": "vj::cascade_tile_pass<false, false>", "grid": "vj::cascade_pass<true, false, *, false, false>",
+        kname = {"tile": "vj::cascade_tile_pass<false, false, true>", "block": "vj::cascade_tile_pass<false, false, false>",
+                 "grid": "vj::cascade_pass<true, false, *, false, false>",
                  "queue": "vj::cascade_pass<false, false, *, false, false>"}
         groups = {}
         for l, ms in zip(launches, launch_ms):
@@ -168,14 +169,14 @@ def main() -> int:
             g["launches"].append(l)
         dom_kind = max(groups, key=lambda k: groups[k]["ms"])
         dom = groups[dom_kind]
+        # algorithmic bytes of the dominant kernel's launches from the counted run's PER-LAUNCH counters
         alg = 0
-        all_scales = sorted({k for l in launches for k in l["scales"]})
-        for l in dom["launches"]:
-            sub = counted if l["scales"] == all_scales else \
-                env.detect(casc, dframes, default_params(flags=VJ_FLAG_COUNTERS, scales=l["scales"]))
+        for l in counted.launches:
+            if l["kind"] != dom_kind:
+                continue
             if l["kind"] != "queue":
-                alg += 48 * sub.windows
-            alg += 16 * sum(sub.stage_entered[st] * rects_per_stage[st] for st in range(l["stage_begin"], l["stage_end"]))
+                alg += 48 * l["stage_entered"][0]
+            alg += 16 * sum(n * rects_per_stage[st] for st, n in enumerate(l["stage_entered"]))
         achieved = alg / (dom["ms"] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")   # from rocprofv3 --pmc passes (tools/pmc_traffic.py)

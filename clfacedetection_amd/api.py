@@ -77,12 +77,13 @@ class _Counters(C.Structure):
 
 VJ_MAX_PASSES = 8
 VJ_MAX_LAUNCHES = 16
-LAUNCH_KINDS = {0: "grid", 1: "queue", 2: "tile"}
+LAUNCH_KINDS = {0: "grid", 1: "queue", 2: "tile", 3: "block"}
 
 
 class _Launch(C.Structure):
     _fields_ = [("kind", C.c_int32), ("lds_class", C.c_int32), ("stage_begin", C.c_int32), ("stage_end", C.c_int32),
-                ("ms", C.c_float), ("lds_bytes", C.c_uint32), ("scale_mask", C.c_uint64 * 2)]
+                ("ms", C.c_float), ("lds_bytes", C.c_uint32), ("scale_mask", C.c_uint64 * 2),
+                ("stage_entered", C.c_uint64 * VJ_MAX_STAGES)]
 
 
 class _Timing(C.Structure):
@@ -351,7 +352,8 @@ class Environment:
                                 [dict(kind=LAUNCH_KINDS.get(int(l.kind), "?"), lds_class=int(l.lds_class),
                                       stage_begin=int(l.stage_begin), stage_end=int(l.stage_end), ms=float(l.ms),
                                       lds_bytes=int(l.lds_bytes),
-                                      scales=[k for k in range(128) if (l.scale_mask[k >> 6] >> (k & 63)) & 1])
+                                      scales=[k for k in range(128) if (l.scale_mask[k >> 6] >> (k & 63)) & 1],
+                                      stage_entered=[int(v) for v in l.stage_entered[:cascade.info.n_stages]])
                                  for l in list(t.launch)[:int(t.n_launches)]])
         finally:
             lib.vj_result_free(C.byref(res))

@@ -30,7 +30,7 @@ struct ScaleDev {
     uint32_t tiles_x;      // tiles per grid row
     uint32_t tile_tw;      // windows per tile row
     uint32_t tile_th;      // window rows per tile (tile_tw * tile_th <= TILE_WAVES * TILE_WAVE_CAP)
-    uint32_t reserved0;
+    uint32_t tile_row_end; // window rows [0, tile_row_end) run on the LDS-tile kernel, the rest on the global-gather path
     uint32_t tile_class;   // LDS size class of the tile launch
     uint32_t tile_half;    // != 0: step is exactly 2 and the tile rows are de-interleaved: even image columns
                            // first, odd columns from element tile_half on (window origins are all even, so a
@@ -59,9 +59,9 @@ static_assert(sizeof(StageDev) == 48, "StageDev is 48 bytes");
 // One unit of first-pass work inside a frame: a run of consecutive windows of one scale.
 struct UnitDev {
     uint32_t scale;        // index into ScaleDev[]
-    uint32_t first;        // first window index (row-major in the scale's grid)
-    uint32_t count;        // <= UNIT_WINDOWS
-    uint32_t pad;
+    uint32_t first;        // first window index (row-major in the scale's grid), or ix0 | iy0 << 16 of a 2-D block
+    uint32_t count;        // <= UNIT_WINDOWS (2-D block: width * height)
+    uint32_t bw;           // 0: a run of consecutive windows; else the width of a 2-D block of windows
 };
 
 // Survivor record handed from one pass to the next: byte offset of the window origin
@@ -172,6 +172,6 @@ constexpr int BAND_ROWS = 8;
 int launch_integral(const IntegralArgs& a, void* stream);
 int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool last, bool count, bool general,
                         int n_blocks, void* stream);
-int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, int n_blocks, void* stream);
+int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, bool staged, int n_blocks, void* stream);
 
 }  // namespace vj

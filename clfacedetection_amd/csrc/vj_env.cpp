@@ -65,6 +65,8 @@ struct Plan {
     std::vector<UnitDev> tile_units;         // first-pass tiles of one frame, grouped by LDS class
     uint32_t class_first[TILE_CLASSES + 1] = {};  // tile_units range of each class
     uint32_t class_lds[TILE_CLASSES] = {};        // dynamic LDS bytes of each class launch
+    uint32_t block_first = 0, n_block_units = 0;  // tile_units range of the unstaged 2-D blocks (global-gather scales)
+    uint32_t block_lds = 0;
     uint32_t tile_end = 0;                        // stage at which the tile launches stop
     uint32_t sp_pad = 0;                          // LDS pitch of the stump-parallel stage table (0 = off)
     std::vector<uint32_t> pass_bounds;       // stage indices: pass p runs [b[p], b[p+1])
@@ -97,6 +99,10 @@ struct vj_env {
     uint32_t det_cap_init = 1u << 16;  // initial capacity of the detection buffer (grows on overflow)
     int concurrent = 1;   // 1: the tile chain and the global-gather chain overlap on two streams
     int concurrent_blocks_per_cu = 1;   // workgroups per CU of the global-gather chain while it overlaps
+    float tile_split = 0.5f;            // scales' worth of tile work handed to the global-gather chain (largest tile scales first)
+    int grid_block_w = 32;              // width of the 2-D window blocks of the global-gather first pass (0: row runs)
+    int global_blocks = 0;              // 1: large scales run as unstaged 2-D blocks in the tile kernel (stump cascades): 2.2x
+                                        // faster than grid + queue passes on its own, but it overlaps the tile chain badly
     int tile_lds_reserve_kb = 18;       // LDS per CU the tile classes leave to the other chain
     char name[256] = "";
     int n_cu = 0;
@@ -334,10 +340,12 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
             sd.te_dw = (int32_t)col((uint32_t)(si.equ_x + si.equ_w)) - (int32_t)col((uint32_t)si.equ_x);
             sd.te_dh = (uint32_t)si.equ_h * sd.tile_pitch;
             sd.tiles_x = (sd.nx + sd.tile_tw - 1) / sd.tile_tw;
+            sd.tile_row_end = sd.ny;
         } else {
-            // global-gather first pass: runs of UNIT_WINDOWS consecutive windows
-            for (uint32_t f = 0; f < sd.nwin; f += UNIT_WINDOWS)
-                pl->units.push_back(UnitDev{slot, f, std::min<uint32_t>(UNIT_WINDOWS, sd.nwin - f), 0});
+            // unstaged in the tile kernel (global_blocks): 2-D blocks of <= 2048 windows, about as wide as high
+            sd.tile_tw = std::min<uint32_t>(sd.nx, 48u);
+            sd.tile_th = std::min<uint32_t>(sd.ny, (uint32_t)(TILE_WAVES * TILE_WAVE_CAP) / sd.tile_tw);
+            sd.tile_row_end = 0;
         }
         pl->scales.push_back(sd);
         pl->scales_info.push_back(si);
@@ -387,6 +395,37 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         }
     }
     pl->n_sp_blocks = (uint32_t)sp_blocks.size();
+    // Balance between the two chains: tile_split scales' worth of tile work (counted from the largest tile
+    // scale down, fractions by window rows) moves to the global-gather chain, which overlaps the tile chain.
+    {
+        double remaining = std::max(0.0, (double)e->tile_split);
+        for (size_t k = pl->scales.size(); k-- > 0 && remaining > 0.0;) {
+            ScaleDev& sd = pl->scales[k];
+            if (!sd.tile_rw) continue;
+            const double move = std::min(1.0, remaining);
+            remaining -= move;
+            const uint32_t keep_rows = (uint32_t)((double)sd.ny * (1.0 - move));
+            sd.tile_row_end = keep_rows / sd.tile_th * sd.tile_th;
+        }
+    }
+    // first-pass units of the global-gather path: whole scales, and the rows of split scales the tiles leave
+    for (uint32_t slot = 0; slot < pl->scales.size(); ++slot) {
+        const ScaleDev& sd = pl->scales[slot];
+        const uint32_t row0 = sd.tile_row_end;
+        if (row0 >= sd.ny) continue;
+        if (e->grid_block_w > 0 && sd.nx < 65536 && sd.ny < 65536) {
+            // 2-D blocks of <= UNIT_WINDOWS windows: a compact footprint in the sum image per wave (a row run
+            // of 512 windows drags a full-width band of 20 s rows through the L2)
+            const uint32_t bw = std::min<uint32_t>((uint32_t)e->grid_block_w, sd.nx);
+            const uint32_t bh = std::max<uint32_t>(1u, std::min<uint32_t>((uint32_t)UNIT_WINDOWS / bw, sd.ny));
+            for (uint32_t iy0 = row0; iy0 < sd.ny; iy0 += bh)
+                for (uint32_t ix0 = 0; ix0 < sd.nx; ix0 += bw)
+                    pl->units.push_back(UnitDev{slot, ix0 | (iy0 << 16), bw * bh, bw});
+        } else {
+            for (uint32_t f = row0 * sd.nx; f < sd.nwin; f += UNIT_WINDOWS)
+                pl->units.push_back(UnitDev{slot, f, std::min<uint32_t>(UNIT_WINDOWS, sd.nwin - f), 0});
+        }
+    }
     pl->pass_bounds = default_pass_bounds(c, pl->prog, e->split_override);
     if (pl->general) pl->pass_bounds = {0u, pl->n_order};  // one pass over StageDev::order (run_stages_general)
     // tile launches run deeper than the global-gather first pass (LDS gathers are ~10x cheaper)
@@ -397,7 +436,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         for (uint32_t slot = 0; slot < pl->scales.size(); ++slot) {
             ScaleDev& sd = pl->scales[slot];
             if (!sd.tile_rw || sd.tile_class != cls) continue;
-            for (uint32_t iy0 = 0; iy0 < sd.ny; iy0 += sd.tile_th)
+            for (uint32_t iy0 = 0; iy0 < sd.tile_row_end; iy0 += sd.tile_th)
                 for (uint32_t ix0 = 0; ix0 < sd.nx; ix0 += sd.tile_tw)
                     pl->tile_units.push_back(UnitDev{slot, ix0 | (iy0 << 16), 0, 0});
             pl->class_lds[cls] = std::max(pl->class_lds[cls], sd.tile_pitch * sd.tile_rows * 4u);
@@ -405,6 +444,16 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         if (pl->class_lds[cls]) pl->class_lds[cls] += tile_header_bytes;
     }
     pl->class_first[TILE_CLASSES] = (uint32_t)pl->tile_units.size();
+    pl->block_first = (uint32_t)pl->tile_units.size();
+    if (!pl->general && !pl->trees)
+        for (uint32_t slot = 0; slot < pl->scales.size(); ++slot) {
+            const ScaleDev& sd = pl->scales[slot];
+            for (uint32_t iy0 = sd.tile_row_end; iy0 < sd.ny; iy0 += sd.tile_th)
+                for (uint32_t ix0 = 0; ix0 < sd.nx; ix0 += sd.tile_tw)
+                    pl->tile_units.push_back(UnitDev{slot, ix0 | (iy0 << 16), 0, 0});
+        }
+    pl->n_block_units = (uint32_t)pl->tile_units.size() - pl->block_first;
+    pl->block_lds = tile_header_bytes;
 
     int rc;
     if ((rc = pl->d_table.ensure(std::max<size_t>(table.size(), 1) * sizeof(NodeRec)))) return rc;
@@ -585,8 +634,10 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
     const size_t n_pass = pl->pass_bounds.size() - 1;
     for (size_t ps = 1; ps < n_pass; ++ps)
         if ((rc = e->d_q[ps].ensure(std::max<uint64_t>(q_entries, 1) * sizeof(QEntry)))) return rc;
-    // counters block: [MAX_PASSES][MAX_SCALES] queue counts | det_count | pad | stage_entered[VJ_MAX_STAGES] (u64)
-    const size_t counts_bytes = (MAX_PASSES * MAX_SCALES + 2) * sizeof(uint32_t) + VJ_MAX_STAGES * sizeof(uint64_t);
+    // counters block: [MAX_PASSES][MAX_SCALES] queue counts | det_count | pad | one stage_entered[VJ_MAX_STAGES]
+    // (u64) array per kernel launch (array 0 is spare)
+    const size_t counts_bytes =
+        (MAX_PASSES * MAX_SCALES + 2) * sizeof(uint32_t) + (size_t)(1 + VJ_MAX_LAUNCHES) * VJ_MAX_STAGES * sizeof(uint64_t);
     if ((rc = e->d_counts.ensure(counts_bytes))) return rc;
     if (e->det_cap == 0) {
         e->det_cap = e->det_cap_init;
@@ -622,7 +673,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.units = (const UnitDev*)pl->d_units.p;
         ca.n_units = (uint32_t)pl->units.size();
         ca.tile_units = (const UnitDev*)pl->d_tile_units.p;
-        ca.n_tile_units = (uint32_t)pl->tile_units.size();
+        ca.n_tile_units = pl->block_first;   // staged tiles; the unstaged blocks follow them in the list
         ca.n_frames = (uint32_t)nf;
         ca.n_scales = (uint32_t)pl->scales.size();
         ca.frame_elems = pl->frame_elems;
@@ -664,12 +715,17 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             li.stage_end = (int32_t)se;
             li.lds_bytes = lds;
             for (const ScaleDev& sd : pl->scales) {
-                const bool in = kind == VJ_LAUNCH_QUEUE || (kind == VJ_LAUNCH_TILE && sd.tile_rw && (int)sd.tile_class == cls) ||
-                                (kind == VJ_LAUNCH_GRID && !sd.tile_rw);
+                const bool in = kind == VJ_LAUNCH_QUEUE ||
+                                (kind == VJ_LAUNCH_TILE && sd.tile_rw && sd.tile_row_end > 0 && (int)sd.tile_class == cls) ||
+                                ((kind == VJ_LAUNCH_GRID || kind == VJ_LAUNCH_BLOCK) && sd.tile_row_end < sd.ny);
                 if (in && sd.scale_idx < 128) li.scale_mask[sd.scale_idx >> 6] |= 1ull << (sd.scale_idx & 63);
             }
             linfo.push_back(li);
             return VJ_OK;
+        };
+        // the launch just begun counts into its own array
+        auto launch_counters = [&]() -> unsigned long long* {
+            return d_stage_entered + std::min<size_t>(linfo.size(), VJ_MAX_LAUNCHES) * VJ_MAX_STAGES;
         };
         auto end_launch = [&](hipStream_t st) -> int {
             if (linfo.size() <= VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(e->launch_ev[2 * linfo.size() - 1], st));
@@ -700,7 +756,8 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             size_t first_joint_pass = 1;
             if (e->tile_min_lanes == 0)
                 while (first_joint_pass < n_pass && pl->pass_bounds[first_joint_pass] < handover) ++first_joint_pass;
-            const bool two_streams = e->concurrent && ca.n_tile_units > 0 && ca.n_units > 0;
+            const bool use_blocks = e->global_blocks && pl->n_block_units > 0 && pl->sp_pad != 0;
+            const bool two_streams = e->concurrent && pl->block_first > 0 && ca.n_units > 0;
             hipStream_t sB = two_streams ? e->stream2 : e->stream;
             if (two_streams) {
                 HIP_TRY(hipEventRecord(e->fork_ev, e->stream));
@@ -722,7 +779,8 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
                 const uint32_t deepest = std::min<uint32_t>((uint32_t)pl->stages.size(), handover);
                 if ((rc = begin_launch(VJ_LAUNCH_TILE, (int)cls, 0, deepest, ta.tile_lds_bytes, e->stream))) return rc;
-                hrc = launch_cascade_tile_pass(ta, pl->trees, count, std::max(1, tb), e->stream);
+                ta.stage_entered = launch_counters();
+                hrc = launch_cascade_tile_pass(ta, pl->trees, count, true, std::max(1, tb), e->stream);
                 if ((rc = end_launch(e->stream))) return rc;
             }
                 return VJ_OK;
@@ -732,16 +790,31 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             // one wave per SIMD), so that the tile workgroups find their LDS share next to it.
             const int b_blocks = two_streams ? std::max(1, e->n_cu * e->concurrent_blocks_per_cu) : n_blocks;
             auto chain_b = [&]() -> int {
-            if (!hrc && ca.n_units > 0) {
+            if (!hrc && use_blocks) {
+                CascadeArgs ta = ca;
+                ta.tile_units = (const UnitDev*)pl->d_tile_units.p + pl->block_first;
+                ta.n_tile_units = pl->n_block_units;
+                ta.tile_lds_bytes = pl->block_lds;
+                ta.tile_ticket = d_qcount[0] + (MAX_SCALES - 1 - TILE_CLASSES);
+                const int per_cu = two_streams ? e->concurrent_blocks_per_cu : 2;
+                const int tb = (int)std::min<uint64_t>((uint64_t)pl->n_block_units * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
+                const uint32_t deepest = std::min<uint32_t>((uint32_t)pl->stages.size(), handover);
+                if ((rc = begin_launch(VJ_LAUNCH_BLOCK, 0, 0, deepest, ta.tile_lds_bytes, sB))) return rc;
+                ta.stage_entered = launch_counters();
+                hrc = launch_cascade_tile_pass(ta, false, count, false, std::max(1, tb), sB);
+                if ((rc = end_launch(sB))) return rc;
+            } else if (!hrc && ca.n_units > 0) {
                 CascadeArgs ga = queue_args(0);
                 ga.total_waves = (uint32_t)b_blocks * WAVES_PER_BLOCK;
                 if ((rc = begin_launch(VJ_LAUNCH_GRID, 0, ga.stage_begin, ga.stage_end, 0, sB))) return rc;
+                ga.stage_entered = launch_counters();
                 hrc = launch_cascade_pass(ga, true, pl->trees, n_pass == 1, count, pl->general, b_blocks, sB);
                 if ((rc = end_launch(sB))) return rc;
                 for (size_t ps = 1; ps < first_joint_pass && !hrc; ++ps) {
                     CascadeArgs qa = queue_args(ps);
                     qa.total_waves = (uint32_t)b_blocks * WAVES_PER_BLOCK;
                     if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, sB))) return rc;
+                    qa.stage_entered = launch_counters();
                     hrc = launch_cascade_pass(qa, false, pl->trees, ps + 1 == n_pass, count, false, b_blocks, sB);
                     if ((rc = end_launch(sB))) return rc;
                 }
@@ -768,6 +841,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 if (ps > first_joint_pass && ps < VJ_MAX_PASSES) HIP_TRY(hipEventRecord(e->pass_ev[ps], e->stream));
                 CascadeArgs qa = queue_args(ps);
                 if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, e->stream))) return rc;
+                qa.stage_entered = launch_counters();
                 hrc = launch_cascade_pass(qa, false, pl->trees, ps + 1 == n_pass, count, false, n_blocks, e->stream);
                 if ((rc = end_launch(e->stream))) return rc;
             }
@@ -810,9 +884,13 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             for (size_t i = 0; i < linfo.size(); ++i) {
                 float ms = 0;
                 HIP_TRY(hipEventElapsedTime(&ms, e->launch_ev[2 * i], e->launch_ev[2 * i + 1]));
-                const float prev = tm->launch[i].ms;
+                vj_launch acc = tm->launch[i];   // sums over sub-batches: time and counters
                 tm->launch[i] = linfo[i];
-                tm->launch[i].ms = prev + ms;
+                tm->launch[i].ms = acc.ms + ms;
+                const unsigned long long* se = (const unsigned long long*)((const uint32_t*)e->h_pinned +
+                                                                           MAX_PASSES * MAX_SCALES + 2) + (1 + i) * VJ_MAX_STAGES;
+                for (size_t s = 0; s < (size_t)VJ_MAX_STAGES; ++s)
+                    tm->launch[i].stage_entered[s] = acc.stage_entered[s] + (count ? se[s] : 0ull);
             }
             tm->n_launches = (int32_t)linfo.size();
         }
@@ -820,13 +898,18 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             const unsigned long long* se =
                 (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * MAX_SCALES + 2);
             fprintf(stderr, "vj stamps:");
-            for (int i = 40; i < 60; ++i) fprintf(stderr, " %llu", se[i]);
+            for (int i = 40; i < 60; ++i) {
+                unsigned long long v = 0;
+                for (int l = 1; l <= VJ_MAX_LAUNCHES; ++l) v += se[l * VJ_MAX_STAGES + i];
+                fprintf(stderr, " %llu", v);
+            }
             fprintf(stderr, "\n");
         }
         if (count) {
             const unsigned long long* se =
                 (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * MAX_SCALES + 2);
-            for (size_t s = 0; s < pl->stages.size(); ++s) ctr->stage_entered[s] += se[s];
+            for (size_t s = 0; s < pl->stages.size(); ++s)
+                for (int l = 1; l <= VJ_MAX_LAUNCHES; ++l) ctr->stage_entered[s] += se[(size_t)l * VJ_MAX_STAGES + s];
         }
         std::vector<DetEntry> raw(n_det);
         if (n_det) HIP_TRY(hipMemcpy(raw.data(), e->d_det.p, (size_t)n_det * sizeof(DetEntry), hipMemcpyDeviceToHost));
@@ -881,7 +964,7 @@ int vj_env_create(int device_index, vj_env** out) {
     HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
-    e->h_pinned_bytes = 8192;
+    e->h_pinned_bytes = 32768;
     HIP_TRY(hipHostMalloc(&e->h_pinned, e->h_pinned_bytes, hipHostMallocDefault));
     if (const char* s = getenv("VJ_BLOCKS_PER_CU")) e->blocks_per_cu = std::max(1, atoi(s));
     if (const char* s = getenv("VJ_PASS_SPLIT")) {  // e.g. "4,9,15"
@@ -1036,6 +1119,22 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "concurrent_blocks_per_cu") == 0) {
         e->concurrent_blocks_per_cu = std::max(1, atoi(value));
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_split") == 0) {
+        e->tile_split = std::max(0.0f, (float)atof(value));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "grid_block_w") == 0) {
+        e->grid_block_w = std::max(0, std::min(atoi(value), (int)UNIT_WINDOWS));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "global_blocks") == 0) {
+        e->global_blocks = atoi(value) != 0;
         return VJ_OK;
     }
     if (strcmp(key, "tile_lds_reserve_kb") == 0) {

@@ -279,15 +279,26 @@ __device__ __forceinline__ float window_variance(rsrc_t sum_f, rsrc_t sq_f, uint
 //    arithmetic; every lane is its own request in the texture-address unit, which is
 //    what bounds this path: ~40-64 cycles per wave-load, measured).
 //  * LdsImg: a tile of the sum image staged in LDS (2-4 cycles per wave-load).
+// The stump-parallel finish turns the roles around — the window offset is wave-uniform, the corner
+// offset differs per lane — which only matters for buffer loads (the scalar operand must be the
+// uniform one): `by_stump()` gives that view.
+struct GlobalImgByStump {
+    rsrc_t r;
+    __device__ __forceinline__ uint32_t ld(uint32_t uni_window_off, uint32_t lane_corner_off) const {
+        return ld_u32(r, lane_corner_off, __builtin_amdgcn_readfirstlane(uni_window_off));
+    }
+};
 struct GlobalImg {
     rsrc_t r;
     __device__ __forceinline__ uint32_t ld(uint32_t lane_off, uint32_t uni_off) const { return ld_u32(r, lane_off, uni_off); }
+    __device__ __forceinline__ GlobalImgByStump by_stump() const { return GlobalImgByStump{r}; }
 };
 struct LdsImg {
     const char* base;  // LDS
     __device__ __forceinline__ uint32_t ld(uint32_t lane_off, uint32_t uni_off) const {
         return *reinterpret_cast<const uint32_t*>(base + (lane_off + uni_off));
     }
+    __device__ __forceinline__ LdsImg by_stump() const { return *this; }
 };
 
 // The weighted rectangle sums of one node (clod.cl:60-76) for the lane's window.
@@ -614,28 +625,41 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
             const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
             const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
             const uint32_t frame_bytes = frame * frame_bytes4;  // < 2^32, checked on the host
-            // precomputeWindows (clod.cpp:495-527): x = lrint(ix * step), row-major
+            // precomputeWindows (clod.cpp:495-527): x = lrint(ix * step); a unit is either a row-major run of
+            // windows or a 2-D block of them (compact footprint in the sum image: the L2 traffic of the
+            // large scales is what bounds this pass)
+            const uint32_t bw = units[r].bw, ny = scales[slot].ny;
+            uint32_t n_q = 0;
             for (uint32_t i0 = 0; i0 < count; i0 += 64u) {
                 const uint32_t i = i0 + lane;
-                if (i < count) {
-                    const uint32_t idx = first + i;
-                    const uint32_t iy = idx / nx;
-                    const uint32_t ix = idx - iy * nx;
+                uint32_t ix, iy;
+                if (bw != 0u) {
+                    const uint32_t ty = i / bw;
+                    ix = (first & 0xffffu) + (i - ty * bw);
+                    iy = (first >> 16) + ty;
+                } else {
+                    iy = (first + i) / nx;
+                    ix = first + i - iy * nx;
+                }
+                const bool valid = i < count && ix < nx && iy < ny;
+                QEntry en{0u, 0.0f};
+                if (valid) {
                     const uint32_t x = (uint32_t)__float2int_rn((float)ix * step);
                     const uint32_t y = (uint32_t)__float2int_rn((float)iy * step);
                     const uint32_t e = y * a.stride + x;
-                    QEntry en;
                     en.var = window_variance(sum_f, sq_f, e, e_lt, e_dw, e_dh, area, a.signed_mean != 0u);
                     en.off = frame_bytes + e * 4u;
-                    q[i] = en;
                 }
+                const unsigned long long mask = __ballot(valid);
+                if (valid) q[n_q + mbcnt(mask)] = en;
+                n_q += (uint32_t)__popcll(mask);
             }
             __builtin_amdgcn_wave_barrier();
             if (GENERAL)
-                run_stages_general<TREES, COUNT>(a, img, q, lds_tgt + wib * UNIT_WINDOWS, count, slot,
+                run_stages_general<TREES, COUNT>(a, img, q, lds_tgt + wib * UNIT_WINDOWS, n_q, slot,
                                                  scales[slot].table_first, lane);
             else
-                run_stages_linear<TREES, LAST, COUNT>(a, img, q, count, slot, scales[slot].table_first,
+                run_stages_linear<TREES, LAST, COUNT>(a, img, q, n_q, slot, scales[slot].table_first,
                                                       scales[slot].q_base, lane, a.stage_begin);
             __builtin_amdgcn_wave_barrier();
         }
@@ -686,8 +710,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
 // clod.cl:81) — exactly the sequence of f32 additions a single lane would have made — compares with the
 // stage threshold, and the survivors are compacted across the waves.  Replaces the serial tail (one thin
 // wave, ~300 cycles per stump) of the late stages.
-template <bool COUNT, bool STAMPS = true>
-__device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, const LdsImg& img,
+template <bool COUNT, bool STAMPS = true, typename Img>
+__device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, const Img& img_by_window,
                                                         const uint32_t* table /* the scale's tile table, global */,
                                                         QEntry* lds_q, unsigned long long* lds_mask, uint32_t* lds_sp,
                                                         uint32_t* lds_cnt, uint32_t T, uint32_t st_begin,
@@ -696,6 +720,7 @@ __device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, co
     unsigned long long sp_acc[5] = {0, 0, 0, 0, 0};
 #define SPSTAMP(ph) do { if (VJ_STAMPS && STAMPS && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); sp_acc[ph] += t_ - t_last; t_last = t_; } } while (0)
 #define SPFLUSH() do { if (VJ_STAMPS && STAMPS && threadIdx.x == 0) { for (int i_ = 0; i_ < 5; ++i_) atomicAdd(a.stage_entered + 54 + i_, sp_acc[i_]); } } while (0)
+    const auto img = img_by_window.by_stump();
     kptr<StageDev> stages = as_k(a.stages);
     kptr<uint32_t> blocks = as_k(reinterpret_cast<const uint32_t*>(a.sp_blocks));   // {first_node, desc} pairs
     const uint32_t tid = wib * 64u + lane;
@@ -918,8 +943,8 @@ __device__ __forceinline__ void node_rect_sum_pair(const Img& img, const NodeRec
 // host's a-priori bound on the difference between ANY two summation orders of the stage); windows
 // inside the band replay their verdict bits in stump order — the reference's exact sequence of f32
 // additions (clod.cl:81).  K = 1 is the plain sequential sum.  Results are bit-identical either way.
-template <bool COUNT>
-__device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const LdsImg& img, kptr<NodeRecDev> table,
+template <bool COUNT, typename Img>
+__device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const Img& img, kptr<NodeRecDev> table,
                                                     QEntry* lds_q, uint32_t* lds_cnt, uint32_t T, uint32_t& st_io,
                                                     uint32_t n_stages, uint32_t lane, uint32_t wib,
                                                     unsigned long long& t_last) {
@@ -1031,7 +1056,7 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
     return T;
 }
 
-template <bool TREES, bool COUNT>
+template <bool TREES, bool COUNT, bool STAGED>
 __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
     QEntry* lds_q = reinterpret_cast<QEntry*>(lds_dyn);                   // TILE_WAVES * TILE_WAVE_CAP entries
@@ -1062,7 +1087,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         const float step = scales[slot].step;
         const uint32_t nx = scales[slot].nx, ny = scales[slot].ny;
         const uint32_t tw = scales[slot].tile_tw, th = scales[slot].tile_th;
-        const uint32_t pitch = scales[slot].tile_pitch, rows = scales[slot].tile_rows;
+        const uint32_t pitch = STAGED ? scales[slot].tile_pitch : 0u, rows = STAGED ? scales[slot].tile_rows : 0u;
+        const uint32_t frame_bytes = frame * frame_bytes4;   // < 2^32, checked on the host
         const size_t frame_off = (size_t)frame * a.frame_elems;
         const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
         const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
@@ -1075,8 +1101,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         // stage the tile: rows round-robin over the waves, 64 consecutive dwords per instruction,
         // straight into LDS (buffer_load ... lds: no VGPR round trip, so every load of the tile is in
         // flight at once instead of one load-wait-store per 256 bytes); the barrier drains them
-        const uint32_t half = scales[slot].tile_half;
-        for (uint32_t rr = wib; rr < rows; rr += TILE_WAVES) {
+        const uint32_t half = STAGED ? scales[slot].tile_half : 0u;
+        for (uint32_t rr = wib; STAGED && rr < rows; rr += TILE_WAVES) {
             const uint32_t g_row = ((y0 + rr) * a.stride + x0) * 4u;   // uniform
             if (half == 0u) {
                 for (uint32_t c0 = 0; c0 < pitch; c0 += 64u) {
@@ -1129,8 +1155,9 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                 const uint32_t x = (uint32_t)__float2int_rn((float)ix * step);
                 const uint32_t y = (uint32_t)__float2int_rn((float)iy * step);
                 // byte offset inside the tile (de-interleaved rows: window origins are even columns)
-                w_lo4[k] = ((y - y0) * pitch + (half ? (x - x0) >> 1 : x - x0)) * 4u;
                 const uint32_t e = y * a.stride + x;
+                // unstaged blocks: byte offset in the batch sum image, as in cascade_pass
+                w_lo4[k] = STAGED ? ((y - y0) * pitch + (half ? (x - x0) >> 1 : x - x0)) * 4u : frame_bytes + e * 4u;
                 const uint32_t c0 = e_lt, c1 = e_lt + e_dw, c2 = e_lt + e_dh, c3 = e_lt + e_dh + e_dw;
                 w_q[k] = ld_u64(sq_f, e * 8u, c0 * 8u) - ld_u64(sq_f, e * 8u, c1 * 8u) - ld_u64(sq_f, e * 8u, c2 * 8u) +
                          ld_u64(sq_f, e * 8u, c3 * 8u);
@@ -1141,14 +1168,23 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
 
         // computeVariance (clod.cpp:418-446): pixel sum from the LDS tile, squared sum as loaded above
         uint32_t n = 0;
-        const LdsImg img{reinterpret_cast<const char*>(lds_img)};
+        typedef typename std::conditional<STAGED, LdsImg, GlobalImg>::type ImgT;
+        ImgT img;
+        if constexpr (STAGED) img = LdsImg{reinterpret_cast<const char*>(lds_img)};
+        else img = GlobalImg{make_rsrc(a.sum, a.sum_bytes)};
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             QEntry en{0u, 0.0f};
             if (w_valid[k]) {
                 const uint32_t lo4 = w_lo4[k];
-                const uint32_t s4 = img.ld(lo4, te_lt) - img.ld(lo4, te_lt + te_dw) - img.ld(lo4, te_lt + te_dh) +
-                                    img.ld(lo4, te_lt + te_dh + te_dw);
+                uint32_t s4;
+                if constexpr (STAGED) {
+                    s4 = img.ld(lo4, te_lt) - img.ld(lo4, te_lt + te_dw) - img.ld(lo4, te_lt + te_dh) +
+                         img.ld(lo4, te_lt + te_dh + te_dw);
+                } else {
+                    const uint32_t g_lt = e_lt * 4u, g_dw = e_dw * 4u, g_dh = e_dh * 4u;
+                    s4 = img.ld(lo4, g_lt) - img.ld(lo4, g_lt + g_dw) - img.ld(lo4, g_lt + g_dh) + img.ld(lo4, g_lt + g_dh + g_dw);
+                }
                 const float mean = (a.signed_mean ? (float)(int32_t)s4 : (float)s4) / area;
                 float variance = (float)w_q[k];
                 variance = (variance / area) - (mean * mean);
@@ -1160,7 +1196,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
             n += (uint32_t)__popcll(mask);
         }
         __builtin_amdgcn_wave_barrier();
-        kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + scales[slot].tile_table_first;
+        const uint32_t table_first = STAGED ? scales[slot].tile_table_first : scales[slot].table_first;
+        kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + table_first;
         // Sweep the cascade stage by stage.  At the stages named by tile_repack_mask and at every
         // pass boundary the tile's survivors are re-packed across its waves into runs of full
         // 64-lane chunks (gathers cost the same for 1 lane as for 64, so 8 thin waves would pay 8x).
@@ -1208,7 +1245,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                                                            wib, t_last);
                     if (left != 0u && s_next < n_stages_total)
                         left = tile_stump_parallel<COUNT, false>(
-                            a, img, a.table + (size_t)scales[slot].tile_table_first * 16u, lds_q,
+                            a, img, a.table + (size_t)table_first * 16u, lds_q,
                             reinterpret_cast<unsigned long long*>(lds_q + TILE_SP_MAX_WINDOWS), lds_tab, lds_cnt, left, s_next,
                             n_stages_total, lane, wib, t_last);
                     q = lds_q;
@@ -1220,7 +1257,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                 if (!TREES && a.tile_finish == 0u && st >= a.tile_sp_begin && total != 0u && total <= a.tile_sp_max) {
                     // few windows left: finish the whole cascade stump-parallel; survivors are detections
                     const uint32_t left = tile_stump_parallel<COUNT, true>(
-                        a, img, a.table + (size_t)scales[slot].tile_table_first * 16u, lds_q,
+                        a, img, a.table + (size_t)table_first * 16u, lds_q,
                         reinterpret_cast<unsigned long long*>(lds_q + TILE_SP_MAX_WINDOWS), lds_tab, lds_cnt, total, st,
                         n_stages_total, lane, wib, t_last);
                     q = lds_q;
@@ -1246,14 +1283,16 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
             if (lane == 0) g = is_det ? atomicAdd(a.det_count, n) : atomicAdd(a.q_pass_count[dest] + slot, n);
             g = __builtin_amdgcn_readfirstlane(g);
             const uint32_t q_base = scales[slot].q_base;
-            const uint32_t frame_bytes = frame * frame_bytes4;
             QEntry* qd = is_det ? nullptr : a.q_pass[dest];
             for (uint32_t i = lane; i < n; i += 64u) {
                 const QEntry e = q[i];
-                const uint32_t lo = e.off >> 2;
-                const uint32_t ly = lo / pitch, lc = lo - ly * pitch;
-                const uint32_t lx = half ? lc * 2u : lc;   // window origins sit in the even plane
-                const uint32_t off = frame_bytes + ((y0 + ly) * a.stride + (x0 + lx)) * 4u;
+                uint32_t off = e.off;
+                if (STAGED) {
+                    const uint32_t lo = e.off >> 2;
+                    const uint32_t ly = lo / pitch, lc = lo - ly * pitch;
+                    const uint32_t lx = half ? lc * 2u : lc;   // window origins sit in the even plane
+                    off = frame_bytes + ((y0 + ly) * a.stride + (x0 + lx)) * 4u;
+                }
                 if (is_det) {
                     if (g + i < a.det_cap) a.det[g + i] = DetEntry{off, slot};
                 } else {
@@ -1269,25 +1308,28 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
     }
 }
 
-int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, int n_blocks, void* stream_) {
+int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, bool staged, int n_blocks, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     static bool attr_set = false;
     if (!attr_set) {  // allow more than the default 64 KiB of dynamic LDS
         const int max_lds = 160 * 1024;
-        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<true, false>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         attr_set = true;
     }
     dim3 g(n_blocks), b(TILE_WAVES * 64);
     const size_t lds = a.tile_lds_bytes;
-    if (trees) {
-        if (count) hipLaunchKernelGGL((cascade_tile_pass<true, true>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((cascade_tile_pass<true, false>), g, b, lds, stream, a);
+    if (!staged) {   // unstaged blocks: stump cascades only (the host keeps tree cascades on cascade_pass)
+        if (count) hipLaunchKernelGGL((cascade_tile_pass<false, true, false>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((cascade_tile_pass<false, false, false>), g, b, lds, stream, a);
+    } else if (trees) {
+        if (count) hipLaunchKernelGGL((cascade_tile_pass<true, true, true>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((cascade_tile_pass<true, false, true>), g, b, lds, stream, a);
     } else {
-        if (count) hipLaunchKernelGGL((cascade_tile_pass<false, true>), g, b, lds, stream, a);
-        else       hipLaunchKernelGGL((cascade_tile_pass<false, false>), g, b, lds, stream, a);
+        if (count) hipLaunchKernelGGL((cascade_tile_pass<false, true, true>), g, b, lds, stream, a);
+        else       hipLaunchKernelGGL((cascade_tile_pass<false, false, true>), g, b, lds, stream, a);
     }
     return (int)hipGetLastError();
 }

@@ -190,14 +190,16 @@ typedef struct vj_counters {
 #define VJ_MAX_LAUNCHES 16
 enum { VJ_LAUNCH_GRID = 0,   /* first pass, windows enumerated from the grid, L2 gathers */
        VJ_LAUNCH_QUEUE = 1,  /* later pass over the survivor queue, L2 gathers           */
-       VJ_LAUNCH_TILE = 2 }; /* first pass(es) on image tiles staged in LDS              */
+       VJ_LAUNCH_TILE = 2,   /* whole cascade on image tiles staged in LDS               */
+       VJ_LAUNCH_BLOCK = 3 };/* whole cascade on 2-D window blocks, L2 gathers (large scales) */
 typedef struct vj_launch {
     int32_t  kind;             /* VJ_LAUNCH_*                                   */
     int32_t  lds_class;        /* tile launches: LDS size class                 */
     int32_t  stage_begin, stage_end;  /* stages it may run (tile launches: up to stage_end) */
     float    ms;               /* HIP-event time, summed over sub-batches       */
     uint32_t lds_bytes;
-    uint64_t scale_mask[2];    /* scale indices it covers (queue passes: all)   */
+    uint64_t scale_mask[2];    /* scale indices it covers, wholly or in part (queue passes: all) */
+    uint64_t stage_entered[VJ_MAX_STAGES];  /* VJ_FLAG_COUNTERS: windows this launch took into each stage */
 } vj_launch;
 typedef struct vj_timing {     /* HIP-event times of the last vj_detect, ms     */
     float integral_ms;         /* the three integral launches                   */

@@ -110,13 +110,21 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         r = env.detect(c, frames, p)
         assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
         env.configure("tile_deinterleave", 1)
-        for conc, reserve in ((0, 18), (0, 0), (1, 0), (1, 40)):
+        for conc, reserve, blocks, split, gbw in ((0, 26, 1, 0, 32), (0, 0, 0, 0.4, 0), (1, 0, 1, 1.3, 32), (1, 40, 0, 2.5, 16),
+                                                  (1, 26, 0, 0.7, 64), (1, 26, 0, 99, 32)):
             env.configure("concurrent", conc)
             env.configure("tile_lds_reserve_kb", reserve)
+            env.configure("global_blocks", blocks)
+            env.configure("tile_split", split)
+            env.configure("grid_block_w", gbw)
             r = env.detect(c, frames, p)
-            assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, (conc, reserve)
+            assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, (conc, reserve, blocks, split)
+            assert [sum(l["stage_entered"][s] for l in r.launches) for s in range(len(r.stage_entered))] == r.stage_entered
         env.configure("concurrent", 1)
         env.configure("tile_lds_reserve_kb", 18)
+        env.configure("global_blocks", 0)
+        env.configure("tile_split", 0.5)
+        env.configure("grid_block_w", 32)
         # LDS-tile path off / small / large tiles / shallow / deep: the tile and the
         # global-gather paths agree bit for bit
         for classes, tile_end, minw in (("0,0,0", 10, 1024), ("24,40,60", 3, 1024), ("36,64,140", 10, 1024),
@@ -138,6 +146,9 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
     finally:
         env.configure("concurrent", 1)
         env.configure("tile_lds_reserve_kb", 18)
+        env.configure("global_blocks", 0)
+        env.configure("tile_split", 0.5)
+        env.configure("grid_block_w", 32)
         env.configure("pass_split", "")
         env.configure("blocks_per_cu", 8)
         env.configure("tile_classes_kb", "-2,-1,0")
@@ -161,6 +172,16 @@ def test_finish_variants_agree(env, cascades):
     try:
         env.configure("tile_sp_begin", 99)
         base = env.detect(c, frames, p)
+        env.configure("tile_sp_begin", 3)
+        env.configure("tile_classes_kb", "0,0,0")   # no LDS tiles: every scale runs as grid pass + queue passes
+        r = env.detect(c, frames, p)
+        assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
+        env.configure("global_blocks", 1)           # ... and as unstaged 2-D blocks in the tile kernel
+        r = env.detect(c, frames, p)
+        assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
+        assert [l["kind"] for l in r.launches] == ["block"]
+        env.configure("global_blocks", 0)
+        env.configure("tile_classes_kb", "-2,-1,0")
         for finish, begin, ws_max, sp_max, ws_min in ((1, 3, 512, 192, 32), (1, 1, 512, 192, 0), (1, 2, 200, 192, 100),
                                                       (1, 5, 64, 192, 8), (1, 3, 512, 192, 256), (0, 3, 512, 192, 32),
                                                       (0, 4, 512, 256, 32)):
@@ -172,6 +193,8 @@ def test_finish_variants_agree(env, cascades):
             r = env.detect(c, frames, p)
             assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, (finish, begin, ws_max)
     finally:
+        env.configure("global_blocks", 0)
+        env.configure("tile_classes_kb", "-2,-1,0")
         env.configure("tile_finish", 1)
         env.configure("tile_sp_begin", 3)
         env.configure("tile_ws_max", 512)

@@ -264,3 +264,58 @@ if "conc6" in what:
     for wsmin, begin in ((32, 3), (64, 3), (48, 2), (48, 4)):
         env.configure("tile_ws_min", wsmin); env.configure("tile_sp_begin", begin); show(f"ws_min {wsmin} begin {begin}")
     env.configure("tile_ws_min", 48); env.configure("tile_sp_begin", 3)
+if "blocks" in what:
+    base = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+    def show(tag):
+        env.detect(c, df, default_params())
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(c, df, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        rc = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+        ok = np.array_equal(rc.rects, base.rects) and rc.stage_entered == base.stage_entered
+        print(f"{tag}: same={ok} wall {wall:.2f} ms cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    for conc in (0, 1):
+        env.configure("concurrent", conc)
+        for gb in (0, 1):
+            env.configure("global_blocks", gb); show(f"concurrent={conc} global_blocks={gb}")
+    env.configure("global_blocks", 1)
+    for bpc in (2, 3):
+        env.configure("concurrent_blocks_per_cu", bpc); show(f"concurrent blocks bpc={bpc}")
+    env.configure("concurrent_blocks_per_cu", 1)
+    for acc in (512, 1024):
+        env.configure("tile_accept_windows", acc); show(f"accept {acc}")
+    env.configure("tile_accept_windows", 768)
+if "grid2d" in what:
+    base = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+    def show(tag):
+        env.detect(c, df, default_params())
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(c, df, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        rc = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+        ok = np.array_equal(rc.rects, base.rects) and rc.stage_entered == base.stage_entered
+        print(f"{tag}: same={ok} wall {wall:.2f} ms cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("global_blocks", 0); env.configure("tile_lds_reserve_kb", 18)
+    for conc in (0, 1):
+        env.configure("concurrent", conc)
+        for bw in (0, 16, 32, 64, 128):
+            env.configure("grid_block_w", bw); show(f"concurrent={conc} grid_block_w={bw}")
+    env.configure("grid_block_w", 32); env.configure("global_blocks", 1); env.configure("tile_lds_reserve_kb", 26)
+if "split2" in what:
+    base = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+    def show(tag):
+        env.detect(c, df, default_params())
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(c, df, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        rc = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+        ok = np.array_equal(rc.rects, base.rects) and rc.stage_entered == base.stage_entered
+        print(f"{tag}: same={ok} wall {wall:.2f} ms cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    env.configure("concurrent", 1)
+    for gb, reserve in ((0, 18), (1, 26)):
+        env.configure("global_blocks", gb); env.configure("tile_lds_reserve_kb", reserve)
+        for acc in (768, 256):
+            env.configure("tile_accept_windows", acc)
+            for sp in (0, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0):
+                env.configure("tile_split", sp); show(f"blocks={gb} reserve={reserve} accept={acc} tile_split={sp}")
+    env.configure("tile_split", 0); env.configure("tile_accept_windows", 768)
