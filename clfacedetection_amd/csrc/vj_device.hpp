@@ -139,6 +139,7 @@ struct CascadeArgs {
     uint32_t  tile_sp_begin;                // >= number of stages: disabled
     uint32_t  tile_sp_pad;                  // dwords of LDS reserved for the finish: two record blocks + leaf values (0 = off)
     uint32_t  tile_sp_max;                  // enter the finish when at most this many windows are left
+    uint32_t  tree2;                        // every tree has exactly two nodes, the second one the child of the first
     uint32_t  tile_finish;                  // 0: stump-parallel finish, 1: wave-split finish (tile_wave_split)
     uint32_t  tile_ws_min;                  // ... and hand over to the stump-parallel finish below this many
     uint32_t  tile_ws_max;                  // enter the wave-split finish when at most this many windows are left

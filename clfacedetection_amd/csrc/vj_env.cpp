@@ -68,6 +68,7 @@ struct Plan {
     uint32_t block_first = 0, n_block_units = 0;  // tile_units range of the unstaged 2-D blocks (global-gather scales)
     uint32_t block_lds = 0;
     uint32_t tile_end = 0;                        // stage at which the tile launches stop
+    bool tree2 = false;                           // every tree: two nodes, node 1 the only node child of node 0
     uint32_t sp_pad = 0;                          // LDS pitch of the stump-parallel stage table (0 = off)
     std::vector<uint32_t> pass_bounds;       // stage indices: pass p runs [b[p], b[p+1])
     uint64_t windows_per_frame = 0;
@@ -190,6 +191,20 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     pl->prog = build_stage_program(c);
     for (const auto& t : c.trees)
         if (t.n_nodes != 1) pl->trees = true;
+    if (pl->trees) {
+        // two-node trees (frontalface_alt2): the tile kernel's wave-split finish knows this shape
+        pl->tree2 = true;
+        for (const auto& t : c.trees) {
+            if (t.n_nodes != 2) { pl->tree2 = false; break; }
+            const vj_node_desc& n0 = c.nodes[t.first_node];
+            const vj_node_desc& n1 = c.nodes[t.first_node + 1];
+            const int kids = (n0.left > 0) + (n0.right > 0);
+            if (kids != 1 || (n0.left > 0 ? n0.left : n0.right) != 1 || n1.left > 0 || n1.right > 0) {
+                pl->tree2 = false;
+                break;
+            }
+        }
+    }
     for (size_t s = 0; s < c.stages.size(); ++s) {
         const bool linear = pl->prog.on_fail[s] == STAGE_REJECT &&
                             (pl->prog.on_pass[s] == (int)s + 1 ||
@@ -694,7 +709,8 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.tile_end = (uint32_t)e->tile_end;
         ca.tile_min_lanes = (uint32_t)e->tile_min_lanes;
         ca.tile_repack_mask = e->tile_repack_mask;
-        ca.tile_sp_begin = pl->sp_pad ? (uint32_t)e->tile_sp_begin : 0xffffffffu;
+        ca.tile_sp_begin = (pl->sp_pad || pl->tree2) ? (uint32_t)e->tile_sp_begin : 0xffffffffu;
+        ca.tree2 = pl->tree2 ? 1u : 0u;
         ca.tile_sp_pad = pl->sp_pad;
         ca.sp_blocks = (const SpBlock*)pl->d_sp_blocks.p;
         ca.n_sp_blocks = pl->n_sp_blocks;

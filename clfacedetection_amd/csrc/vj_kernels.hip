@@ -469,6 +469,32 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
         kptr<NodeRecDev> tab = table + first_node;
         uint32_t m = 0;
         uint32_t base = 0;
+        if (TREES && MULTI && a.tree2) {
+            // two-node trees: pairs of chunks share the record fetches
+            while (base + 64u < n) {
+                QEntry e[2];
+                uint32_t off[2];
+                float var[2], sum[2];
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const uint32_t i = base + (uint32_t)c * 64u + lane;
+                    e[c] = q[i < n ? i : 0u];
+                    off[c] = e[c].off;
+                    var[c] = e[c].var;
+                }
+                stage_sum_tree2_multi<2>(img, tab, n_nodes >> 1, off, var, sum);
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int c = 0; c < 2; ++c) {
+                    const bool pass = base + (uint32_t)c * 64u + lane < n && sum[c] >= threshold;
+                    const unsigned long long mask = __ballot(pass);
+                    if (pass) q[m + mbcnt(mask)] = e[c];
+                    m += (uint32_t)__popcll(mask);
+                }
+                __builtin_amdgcn_wave_barrier();
+                base += 128u;
+            }
+        }
         if (!TREES && MULTI) {
             // groups of 4, then 2 full-or-partial chunks; a last single chunk falls through to the loop below
             auto group = [&](auto nc_tag) {
@@ -503,7 +529,17 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
             const bool act = i < n;
             const QEntry e = q[act ? i : 0u];
             bool pass = false;
-            if (act) pass = stage_sum_of<TREES>(img, tab, n_nodes, e.off, e.var) >= threshold;
+            if (act) {
+                if (TREES && MULTI && a.tree2) {
+                    const uint32_t off1[1] = {e.off};
+                    const float var1[1] = {e.var};
+                    float sum1[1];
+                    stage_sum_tree2_multi<1>(img, tab, n_nodes >> 1, off1, var1, sum1);
+                    pass = sum1[0] >= threshold;
+                } else {
+                    pass = stage_sum_of<TREES>(img, tab, n_nodes, e.off, e.var) >= threshold;
+                }
+            }
             const unsigned long long mask = __ballot(pass);
             __builtin_amdgcn_wave_barrier();   // every lane has read its entry before any lane overwrites
             if (pass) q[m + mbcnt(mask)] = e;  // m + rank <= i: never ahead of the read cursor
@@ -932,6 +968,47 @@ __device__ __forceinline__ void node_rect_sum_pair(const Img& img, const NodeRec
     sum_b = out[1];
 }
 
+// A two-node tree (root r0, its only node child r1, leaves elsewhere — every tree of frontalface_alt2) on
+// one window: icvEvalHidHaarClassifier's walk (tempcv.cpp:771-792: idx = sum < t ? left : right) with both
+// nodes' gathers in flight together.  Returns the leaf value; `code` names the leaf (bit 1: reached through
+// the child, bit 0: right side) so that an ordered replay can pick the same value again.
+template <typename Img>
+__device__ __forceinline__ float tree2_value(const Img& img, const NodeRecDev& r0, const NodeRecDev& r1, uint32_t off,
+                                             float var, uint32_t& code) {
+    float s0, s1;
+    node_rect_sum_pair(img, r0, r1, off, s0, s1);
+    const uint32_t flags0 = r0[7] >> 16;
+    const bool left0 = s0 < __uint_as_float(r0[11]) * var;
+    const bool left1 = s1 < __uint_as_float(r1[11]) * var;
+    const bool to_child = left0 ? (flags0 & 1u) != 0u : (flags0 & 2u) != 0u;
+    const float leaf0 = left0 ? __uint_as_float(r0[12]) : __uint_as_float(r0[13]);
+    const float leaf1 = left1 ? __uint_as_float(r1[12]) : __uint_as_float(r1[13]);
+    code = to_child ? (left1 ? 2u : 3u) : (left0 ? 0u : 1u);
+    return to_child ? leaf1 : leaf0;
+}
+
+// One stage of two-node trees on NC chunks of windows: the two records of a tree are fetched once for all
+// chunks (next tree prefetched); per window the values are added in tree order, as stage_sum_trees does.
+template <int NC, typename Img>
+__device__ __forceinline__ void stage_sum_tree2_multi(const Img& img, kptr<NodeRecDev> tab, uint32_t n_trees,
+                                                      const uint32_t (&off)[NC], const float (&var)[NC],
+                                                      float (&stage_sum)[NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) stage_sum[c] = 0.0f;
+    NodeRecDev r0 = tab[0], r1 = tab[1];
+    for (uint32_t t = 0; t < n_trees; ++t) {
+        const uint32_t tn = t + 1u < n_trees ? t + 1u : t;
+        const NodeRecDev n0 = tab[2u * tn], n1 = tab[2u * tn + 1u];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            uint32_t code;
+            stage_sum[c] += tree2_value(img, r0, r1, off[c], var[c], code);
+        }
+        r0 = n0;
+        r1 = n1;
+    }
+}
+
 // Wave-split finish of a tile (stump cascades).  T <= TILE_WS_MAX_WINDOWS packed survivors sit in
 // lds_q[0, T): c = ceil(T / 64) chunks.  Thin tiles are latency-bound when one wave walks a whole
 // stage for its chunk while the others idle, so the stage's stumps are split into K = 8 / c
@@ -943,7 +1020,7 @@ __device__ __forceinline__ void node_rect_sum_pair(const Img& img, const NodeRec
 // host's a-priori bound on the difference between ANY two summation orders of the stage); windows
 // inside the band replay their verdict bits in stump order — the reference's exact sequence of f32
 // additions (clod.cl:81).  K = 1 is the plain sequential sum.  Results are bit-identical either way.
-template <bool COUNT, typename Img>
+template <bool COUNT, bool TREE2, typename Img>
 __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const Img& img, kptr<NodeRecDev> table,
                                                     QEntry* lds_q, uint32_t* lds_cnt, uint32_t T, uint32_t& st_io,
                                                     uint32_t n_stages, uint32_t lane, uint32_t wib,
@@ -957,14 +1034,16 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
     // below tile_ws_min windows a chunk's lanes are mostly empty: the caller continues stump-parallel
     for (; s < n_stages && T != 0u && T >= a.tile_ws_min; ++s) {
         if (COUNT && threadIdx.x == 0) atomicAdd(a.stage_entered + s, (unsigned long long)T);
-        const uint32_t n = stages[s].n_nodes;
+        // items of a stage: stumps, or two-node trees (TREE2: records 2t and 2t+1, a 2-bit leaf code per tree)
+        constexpr uint32_t PER_WORD = TREE2 ? 16u : 32u;
+        const uint32_t n = TREE2 ? stages[s].n_nodes >> 1 : stages[s].n_nodes;
         const float thr_s = stages[s].threshold, delta = stages[s].sp_delta;
         kptr<NodeRecDev> tab = table + stages[s].first_node;
         const uint32_t c = (T + 63u) >> 6;
         uint32_t K = (uint32_t)TILE_WAVES / c;
         uint32_t rs = (n + K - 1u) / K;
         rs = (rs + 1u) & ~1u;                      // even: pairs never straddle two ranges
-        if (rs > 128u || K == 1u) { K = 1u; rs = n; }
+        if (rs > 4u * PER_WORD || K == 1u) { K = 1u; rs = n; }
         const uint32_t chunk = wib % c, range = wib / c;   // uniform
         const uint32_t i = chunk * 64u + lane;
         const bool valid = i < T;
@@ -972,35 +1051,61 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
         bool pass = false;
         if (range < K) {
             if (K == 1u) {
-                pass = valid && stage_sum_stumps(img, tab, n, e.off, e.var) >= thr_s;
+                if (TREE2) {
+                    const uint32_t off1[1] = {e.off};
+                    const float var1[1] = {e.var};
+                    float sum1[1];
+                    stage_sum_tree2_multi<1>(img, tab, n, off1, var1, sum1);
+                    pass = valid && sum1[0] >= thr_s;
+                } else {
+                    pass = valid && stage_sum_stumps(img, tab, n, e.off, e.var) >= thr_s;
+                }
             } else {
                 const uint32_t j0 = min(range * rs, n), j1 = min(j0 + rs, n);
                 float psum = 0.0f;
                 uint32_t* xw = lds_x + wib * 320u;   // [0,64) sums, [64 + 64 w, ...) verdict word w
-                for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += 32u, ++wd) {
-                    const uint32_t m = min(32u, j1 - w0);
-                    uint32_t bw = 0u;
-                    uint32_t k = 0;
-                    NodeRecDev ra = tab[w0], rb = tab[min(w0 + 1u, j1 - 1u)];
-                    for (; k + 1u < m; k += 2u) {
-                        // the next pair's records travel while this pair is evaluated
-                        const NodeRecDev na = tab[min(w0 + k + 2u, j1 - 1u)], nb = tab[min(w0 + k + 3u, j1 - 1u)];
-                        float sa, sb;
-                        node_rect_sum_pair(img, ra, rb, e.off, sa, sb);
-                        const bool pa = sa >= __uint_as_float(ra[11]) * e.var, pb = sb >= __uint_as_float(rb[11]) * e.var;
-                        psum += pa ? __uint_as_float(ra[13]) : __uint_as_float(ra[12]);
-                        psum += pb ? __uint_as_float(rb[13]) : __uint_as_float(rb[12]);
-                        bw |= (pa ? 1u : 0u) << k;
-                        bw |= (pb ? 2u : 0u) << k;
-                        ra = na;
-                        rb = nb;
+                if (TREE2) {
+                    for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += PER_WORD, ++wd) {
+                        const uint32_t m = min(PER_WORD, j1 - w0);
+                        uint32_t bw = 0u;
+                        NodeRecDev r0 = tab[2u * w0], r1 = tab[2u * w0 + 1u];
+                        for (uint32_t k = 0; k < m; ++k) {
+                            const uint32_t tn = min(w0 + k + 1u, j1 - 1u);
+                            const NodeRecDev n0 = tab[2u * tn], n1 = tab[2u * tn + 1u];
+                            uint32_t code;
+                            psum += tree2_value(img, r0, r1, e.off, e.var, code);
+                            bw |= code << (2u * k);
+                            r0 = n0;
+                            r1 = n1;
+                        }
+                        xw[64u + wd * 64u + lane] = bw;
                     }
-                    if (k < m) {   // odd tail (only the last word of the stage's last range)
-                        const bool pa = node_rect_sum(img, ra, e.off) >= __uint_as_float(ra[11]) * e.var;
-                        psum += pa ? __uint_as_float(ra[13]) : __uint_as_float(ra[12]);
-                        bw |= (pa ? 1u : 0u) << k;
+                } else {
+                    for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += 32u, ++wd) {
+                        const uint32_t m = min(32u, j1 - w0);
+                        uint32_t bw = 0u;
+                        uint32_t k = 0;
+                        NodeRecDev ra = tab[w0], rb = tab[min(w0 + 1u, j1 - 1u)];
+                        for (; k + 1u < m; k += 2u) {
+                            // the next pair's records travel while this pair is evaluated
+                            const NodeRecDev na = tab[min(w0 + k + 2u, j1 - 1u)], nb = tab[min(w0 + k + 3u, j1 - 1u)];
+                            float sa, sb;
+                            node_rect_sum_pair(img, ra, rb, e.off, sa, sb);
+                            const bool pa = sa >= __uint_as_float(ra[11]) * e.var, pb = sb >= __uint_as_float(rb[11]) * e.var;
+                            psum += pa ? __uint_as_float(ra[13]) : __uint_as_float(ra[12]);
+                            psum += pb ? __uint_as_float(rb[13]) : __uint_as_float(rb[12]);
+                            bw |= (pa ? 1u : 0u) << k;
+                            bw |= (pb ? 2u : 0u) << k;
+                            ra = na;
+                            rb = nb;
+                        }
+                        if (k < m) {   // odd tail (only the last word of the stage's last range)
+                            const bool pa = node_rect_sum(img, ra, e.off) >= __uint_as_float(ra[11]) * e.var;
+                            psum += pa ? __uint_as_float(ra[13]) : __uint_as_float(ra[12]);
+                            bw |= (pa ? 1u : 0u) << k;
+                        }
+                        xw[64u + wd * 64u + lane] = bw;
                     }
-                    xw[64u + wd * 64u + lane] = bw;
                 }
                 xw[lane] = __float_as_uint(psum);
             }
@@ -1021,12 +1126,22 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
                     for (uint32_t r = 0; r < K; ++r) {
                         const uint32_t j0 = min(r * rs, n), j1 = min(j0 + rs, n);
                         const uint32_t* xw = lds_x + (r * c + wib) * 320u + 64u;
-                        for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += 32u, ++wd) {
-                            const uint32_t m = min(32u, j1 - w0);
+                        for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += PER_WORD, ++wd) {
+                            const uint32_t m = min(PER_WORD, j1 - w0);
                             const uint32_t bw = xw[wd * 64u + lane];
-                            kptr<uint32_t> lr = reinterpret_cast<kptr<uint32_t>>(tab + w0);
-                            for (uint32_t k = 0; k < m; ++k)
-                                sum += (bw >> k) & 1u ? __uint_as_float(lr[k * 16u + 13u]) : __uint_as_float(lr[k * 16u + 12u]);
+                            if (TREE2) {
+                                kptr<uint32_t> lr = reinterpret_cast<kptr<uint32_t>>(tab + 2u * w0);
+                                for (uint32_t k = 0; k < m; ++k) {
+                                    const uint32_t code = (bw >> (2u * k)) & 3u;
+                                    const float l0 = __uint_as_float(lr[k * 32u + 12u]), r0 = __uint_as_float(lr[k * 32u + 13u]);
+                                    const float l1 = __uint_as_float(lr[k * 32u + 28u]), r1 = __uint_as_float(lr[k * 32u + 29u]);
+                                    sum += code & 2u ? (code & 1u ? r1 : l1) : (code & 1u ? r0 : l0);
+                                }
+                            } else {
+                                kptr<uint32_t> lr = reinterpret_cast<kptr<uint32_t>>(tab + w0);
+                                for (uint32_t k = 0; k < m; ++k)
+                                    sum += (bw >> k) & 1u ? __uint_as_float(lr[k * 16u + 13u]) : __uint_as_float(lr[k * 16u + 12u]);
+                            }
                         }
                     }
                     if (!clear) pass = valid && sum >= thr_s;
@@ -1238,12 +1353,13 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                 q = lds_q + first;
                 n = min(share, total - first);
                 STAMP(3 + min(st, 8u));   // time of stage st-1 (incl. waiting for the slowest wave) + this re-pack
-                if (!TREES && a.tile_finish == 1u && st >= a.tile_sp_begin && total != 0u && total <= a.tile_ws_max) {
-                    // few windows left: finish the whole cascade with the stage's stumps split over the waves
+                if ((!TREES || a.tree2) && a.tile_finish == 1u && st >= a.tile_sp_begin && total != 0u && total <= a.tile_ws_max) {
+                    // few windows left: finish the whole cascade with the stage's stumps (or two-node trees) split
+                    // over the waves
                     uint32_t s_next = st;
-                    uint32_t left = tile_wave_split<COUNT>(a, img, table, lds_q, lds_cnt, total, s_next, n_stages_total, lane,
-                                                           wib, t_last);
-                    if (left != 0u && s_next < n_stages_total)
+                    uint32_t left = tile_wave_split<COUNT, TREES>(a, img, table, lds_q, lds_cnt, total, s_next, n_stages_total,
+                                                                  lane, wib, t_last);
+                    if (!TREES && left != 0u && s_next < n_stages_total)
                         left = tile_stump_parallel<COUNT, false>(
                             a, img, a.table + (size_t)table_first * 16u, lds_q,
                             reinterpret_cast<unsigned long long*>(lds_q + TILE_SP_MAX_WINDOWS), lds_tab, lds_cnt, left, s_next,

@@ -153,7 +153,17 @@ int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
  * "blocks_per_cu" = persistent workgroups per CU of the global-gather passes,
  * "tile_classes_kb" = "a,b,c" LDS budgets of the image-tile launches ("0,0,0"
  * turns the LDS-tile path off), "tile_end" = stage at which tile launches stop,
- * "tile_min_windows" = windows per tile that make a class acceptable.           */
+ * "tile_min_windows" / "tile_accept_windows" = windows per tile that make a class
+ * acceptable / a scale eligible for tiles, "tile_lds_reserve_kb" = LDS per CU left
+ * to the global-gather chain, "concurrent" = 0/1 overlap the two chains on two
+ * streams, "concurrent_blocks_per_cu", "tile_split" = scales' worth of tile work
+ * handed to the gather chain, "grid_block_w" = width of the 2-D window blocks of the
+ * gather chain's first pass (0: row runs), "global_blocks" = 0/1 large scales as
+ * unstaged blocks in the tile kernel, "tile_repack" = stages before which a tile
+ * re-packs, "tile_finish" (0 stump-parallel only, 1 wave-split first),
+ * "tile_sp_begin", "tile_sp_max", "tile_ws_min", "tile_ws_max" = finish
+ * thresholds, "tile_deinterleave", "tile_min_lanes", "max_subbatch", "det_cap".
+ * Unknown keys return VJ_ERR_ARG.                                               */
 int  vj_env_configure(vj_env* e, const char* key, const char* value);
 
 /* --------------------------------------------------------------- integral */

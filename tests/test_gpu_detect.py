@@ -53,7 +53,8 @@ def test_survey_pin_on_gpu(env, oracle, cascades):
 
 
 @pytest.mark.parametrize("casc,kind,h,w", [("frontalface_alt", "noise", 1080, 1920), ("frontalface_alt", "smooth", 720, 1280),
-                                           ("frontalface_default", "blocks", 600, 800), ("eye", "noise", 480, 640)])
+                                           ("frontalface_default", "blocks", 600, 800), ("eye", "noise", 480, 640),
+                                           ("frontalface_alt2", "noise", 720, 1280), ("frontalface_alt2", "blocks", 540, 960)])
 def test_detect_matches_live_oracle_large(env, oracle, cascades, casc, kind, h, w):
     c, a = cascades(casc)
     img = synth.frame(kind, 900 + h, h, w)
@@ -162,10 +163,12 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("tile_ws_max", 512)
 
 
-def test_finish_variants_agree(env, cascades):
+@pytest.mark.parametrize("casc", ["frontalface_alt", "frontalface_alt2"])
+def test_finish_variants_agree(env, cascades, casc):
     """The stump-parallel and the wave-split finish of the tile kernel (and neither) give the same rectangles and
-    per-stage counts as the oracle-checked default, on frames that keep many windows alive (noise) and few (smooth)."""
-    c, _ = cascades("frontalface_alt")
+    per-stage counts as the oracle-checked default, on frames that keep many windows alive (noise) and few (smooth).
+    frontalface_alt2 (two-node trees) takes the wave-split finish only."""
+    c, _ = cascades(casc)
     frames = np.stack([make_frame("noise", 31, 540, 960), make_frame("smooth", 32, 540, 960),
                        make_frame("blocks", 33, 540, 960)])
     p = default_params(flags=VJ_FLAG_COUNTERS)
@@ -179,7 +182,7 @@ def test_finish_variants_agree(env, cascades):
         env.configure("global_blocks", 1)           # ... and as unstaged 2-D blocks in the tile kernel
         r = env.detect(c, frames, p)
         assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
-        assert [l["kind"] for l in r.launches] == ["block"]
+        assert [l["kind"] for l in r.launches] == (["block"] if casc == "frontalface_alt" else ["grid", "queue", "queue"])
         env.configure("global_blocks", 0)
         env.configure("tile_classes_kb", "-2,-1,0")
         for finish, begin, ws_max, sp_max, ws_min in ((1, 3, 512, 192, 32), (1, 1, 512, 192, 0), (1, 2, 200, 192, 100),

@@ -319,3 +319,17 @@ if "split2" in what:
             for sp in (0, 0.25, 0.5, 0.75, 1.0, 1.5, 2.0):
                 env.configure("tile_split", sp); show(f"blocks={gb} reserve={reserve} accept={acc} tile_split={sp}")
     env.configure("tile_split", 0); env.configure("tile_accept_windows", 768)
+if "configs" in what:
+    for name, cas, W, H, nb in (("config5 alt2 720p", "frontalface_alt2", 1280, 720, 64), ("config4 alt_tree 4096^2", "frontalface_alt_tree", 4096, 4096, 2),
+                                ("default 1080p", "frontalface_default", 1920, 1080, 32), ("eye 1080p", "eye", 1920, 1080, 32)):
+        cc = Cascade.load(cas)
+        fr = synth.batch(nb, H, W, seed0=1)
+        tt = torch.from_numpy(fr).cuda(); torch.cuda.synchronize()
+        dd = DeviceFrames.from_torch(tt)
+        env.detect(cc, dd, default_params())
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(cc, dd, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        rc = env.detect(cc, dd, default_params(flags=VJ_FLAG_COUNTERS))
+        print(f"{name}: {nb} frames wall {wall:.2f} ms -> {rc.windows/wall/1e6:.2f} Gwin/s, {rc.stump_evals/max(rc.windows,1):.1f} evals/win, {rc.stump_evals/wall/1e6:.1f} Gevals/s, dets {len(r.rects)} " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+        del tt, dd
