@@ -67,7 +67,7 @@ class ScaleInfo(C.Structure):
 
 class _Image(C.Structure):
     _fields_ = [("data", C.c_void_p), ("width", C.c_int32), ("height", C.c_int32), ("stride", C.c_int32),
-                ("on_device", C.c_int32)]
+                ("on_device", C.c_int32), ("channels", C.c_int32)]
 
 
 class _Counters(C.Structure):
@@ -131,6 +131,7 @@ _SIGNATURES = {
     "vj_env_device_name": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "vj_env_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "vj_integral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
+    "vj_integral_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vj_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.POINTER(Params),
                             C.POINTER(_Result)]),
     "vj_result_free": (None, [C.POINTER(_Result)]),
@@ -300,19 +301,27 @@ class Environment:
         _check(load_library().vj_env_reserve(self._h, width, height, batch), "vj_env_reserve")
 
     def integral(self, gray: np.ndarray) -> tuple[np.ndarray, np.ndarray]:
-        if gray.dtype != np.uint8 or gray.ndim != 2:
-            raise ValueError("integral expects a 2-D uint8 image")
+        """clifIntegral on a 2-D uint8 image; a 3-D (h, w, 3 | 4) BGR / BGRA image goes through
+        clifGrayscaleIntegral's conversion first (vj_integral_image)."""
+        if gray.dtype != np.uint8 or gray.ndim not in (2, 3):
+            raise ValueError("integral expects a 2-D uint8 image or a (h, w, 3|4) uint8 BGR/BGRA image")
+        s = np.empty((gray.shape[0] + 1, gray.shape[1] + 1), np.uint32)
+        q = np.empty((gray.shape[0] + 1, gray.shape[1] + 1), np.uint64)
+        if gray.ndim == 3:
+            g = _pixel_contiguous(gray)
+            im = _Image(g.ctypes.data, g.shape[1], g.shape[0], g.strides[0], 0, g.shape[2])
+            _check(load_library().vj_integral_image(self._h, C.byref(im), s.ctypes.data, q.ctypes.data), "vj_integral_image")
+            return s, q
         g = gray if gray.strides[1] == 1 else np.ascontiguousarray(gray)
         h, w = g.shape
-        s = np.empty((h + 1, w + 1), np.uint32)
-        q = np.empty((h + 1, w + 1), np.uint64)
         _check(load_library().vj_integral(self._h, g.ctypes.data, w, h, g.strides[0], s.ctypes.data, q.ctypes.data),
                "vj_integral")
         return s, q
 
-    def detect(self, cascade: Cascade, frames, params: Params | None = None) -> DetectResult:
+    def detect(self, cascade: Cascade, frames, params: Params | None = None, color: bool = False) -> DetectResult:
         """frames: 2-D uint8 array, 3-D (n, h, w) array, list of 2-D arrays, or
-        DeviceFrames (frames already resident in HBM)."""
+        DeviceFrames (frames already resident in HBM).  color=True: every frame is (h, w, 3 | 4) BGR / BGRA
+        (one 3-D array, a 4-D batch or a list) and is converted to gray on the device."""
         p = params or default_params()
         keep = []
         if isinstance(frames, DeviceFrames):
@@ -320,19 +329,26 @@ class Environment:
             imgs = (_Image * max(n, 1))()
             for i in range(n):
                 imgs[i] = _Image(frames.ptr + i * frames.stride * frames.height, frames.width, frames.height,
-                                 frames.stride, 1)
+                                 frames.stride, 1, frames.channels)
         else:
-            if isinstance(frames, np.ndarray) and frames.ndim == 2:
+            if isinstance(frames, np.ndarray) and frames.ndim == (3 if color else 2):
                 frames = [frames]
             frames = list(frames)
             n = len(frames)
             imgs = (_Image * max(n, 1))()
             for i, f in enumerate(frames):
+                if color:
+                    if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] not in (3, 4):
+                        raise ValueError("color frames must be (h, w, 3|4) uint8 (BGR / BGRA)")
+                    g = _pixel_contiguous(f)
+                    keep.append(g)
+                    imgs[i] = _Image(g.ctypes.data, g.shape[1], g.shape[0], g.strides[0], 0, g.shape[2])
+                    continue
                 if f.dtype != np.uint8 or f.ndim != 2:
                     raise ValueError("frames must be 2-D uint8 (8-bit single channel)")
                 g = f if f.strides[1] == 1 else np.ascontiguousarray(f)
                 keep.append(g)
-                imgs[i] = _Image(g.ctypes.data, g.shape[1], g.shape[0], g.strides[0], 0)
+                imgs[i] = _Image(g.ctypes.data, g.shape[1], g.shape[0], g.strides[0], 0, 1)
         res = _Result()
         lib = load_library()
         _check(lib.vj_detect(self._h, cascade._h, imgs, n, C.byref(p), C.byref(res)), "vj_detect")
@@ -374,18 +390,30 @@ class Environment:
 class DeviceFrames:
     """A batch of equal-size 8-bit frames already resident in device memory
     (e.g. a torch.uint8 CUDA tensor's data_ptr()); rows `stride` bytes apart,
-    frames `stride * height` bytes apart."""
+    frames `stride * height` bytes apart; channels = 1 (gray), 3 (BGR) or 4 (BGRA), interleaved."""
     ptr: int
     n: int
     height: int
     width: int
     stride: int
+    channels: int = 1
 
     @classmethod
     def from_torch(cls, t) -> "DeviceFrames":
-        assert t.is_cuda and t.dtype.itemsize == 1 and t.dim() == 3 and t.is_contiguous()
+        """(n, h, w) gray or (n, h, w, 3 | 4) BGR / BGRA uint8 CUDA tensor."""
+        assert t.is_cuda and t.dtype.itemsize == 1 and t.dim() in (3, 4) and t.is_contiguous()
+        if t.dim() == 4:
+            n, h, w, ch = t.shape
+            assert ch in (3, 4)
+            return cls(t.data_ptr(), n, h, w, w * ch, ch)
         n, h, w = t.shape
         return cls(t.data_ptr(), n, h, w, w)
+
+
+def _pixel_contiguous(img: np.ndarray) -> np.ndarray:
+    """(h, w, c) view whose pixels and channels are contiguous (rows may be strided: ROI views stay views)."""
+    c = img.shape[2]
+    return img if img.strides[2] == 1 and img.strides[1] == c else np.ascontiguousarray(img)
 
 
 def group_rectangles(rects: np.ndarray, group_threshold: int, eps: float = 0.2) -> np.ndarray:

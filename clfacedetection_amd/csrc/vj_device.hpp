@@ -156,6 +156,7 @@ struct IntegralArgs {
     const uint8_t* gray;        // batch of frames
     uint64_t gray_frame_bytes;  // distance between frames
     uint32_t gray_stride;       // bytes per row
+    uint32_t channels;          // 1: gray; 3: BGR, 4: BGRA (converted on the fly)
     uint32_t width, height;
     uint32_t n_frames;
     uint32_t n_bands;           // ceil(height / BAND_ROWS)

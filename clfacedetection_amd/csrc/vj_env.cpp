@@ -535,7 +535,7 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
     return VJ_OK;
 }
 
-static int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_gray) {
+static int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_gray, int channels = 1) {
     const size_t fe = frame_elems_for(W, H);
     const uint32_t n_bands = ((uint32_t)H + BAND_ROWS - 1) / BAND_ROWS;
     const uint32_t band_pitch = ((uint32_t)W + 3u) & ~3u;
@@ -546,7 +546,7 @@ static int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_g
     if ((rc = e->d_sqsum.ensure(sq_bytes))) return rc;
     (void)grow;
     if (need_gray) {
-        const size_t gstride = ((size_t)W + 3) & ~(size_t)3;
+        const size_t gstride = ((size_t)W * (size_t)channels + 3) & ~(size_t)3;
         if ((rc = e->d_gray.ensure(gstride * (size_t)H * (size_t)frames))) return rc;
     }
     const size_t band_elems = (size_t)frames * n_bands * band_pitch;
@@ -557,9 +557,11 @@ static int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_g
 }
 
 // Enqueue the three integral kernels for `frames` frames already on the device.
-static int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int stride, int W, int H, int frames) {
+static int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int stride, int W, int H, int frames,
+                            int channels = 1) {
     IntegralArgs ia;
     memset(&ia, 0, sizeof(ia));
+    ia.channels = (uint32_t)channels;
     ia.gray = d_gray;
     ia.gray_frame_bytes = frame_bytes;
     ia.gray_stride = (uint32_t)stride;
@@ -602,8 +604,11 @@ static int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes
 
 // Upload host frames (or gather strided device frames) into d_gray with a 4-byte
 // aligned pitch.  Returns the device pointer / pitch the integral kernels should use.
+static inline int image_channels(const vj_image& im) { return im.channels <= 1 ? 1 : im.channels; }
+
 static int stage_frames(vj_env* e, const vj_image* frames, int n, int W, int H, const uint8_t** d_ptr,
                         size_t* frame_bytes, int* stride) {
+    const size_t row_bytes = (size_t)W * (size_t)image_channels(frames[0]);
     bool all_dev = true, contiguous = true;
     for (int i = 0; i < n; ++i) {
         if (!frames[i].on_device) all_dev = false;
@@ -617,10 +622,10 @@ static int stage_frames(vj_env* e, const vj_image* frames, int n, int W, int H, 
         *frame_bytes = (size_t)frames[0].stride * (size_t)H;
         return VJ_OK;
     }
-    const size_t gstride = ((size_t)W + 3) & ~(size_t)3;
+    const size_t gstride = (row_bytes + 3) & ~(size_t)3;
     for (int i = 0; i < n; ++i) {
         uint8_t* dst = (uint8_t*)e->d_gray.p + (size_t)i * gstride * (size_t)H;
-        HIP_TRY(hipMemcpy2DAsync(dst, gstride, frames[i].data, (size_t)frames[i].stride, (size_t)W, (size_t)H,
+        HIP_TRY(hipMemcpy2DAsync(dst, gstride, frames[i].data, (size_t)frames[i].stride, row_bytes, (size_t)H,
                                  frames[i].on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
     }
     *d_ptr = (const uint8_t*)e->d_gray.p;
@@ -643,7 +648,8 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         if (!frames[f0 + i].on_device) need_gray = true;
     // strided / scattered device frames are gathered too
     need_gray = true;
-    if ((rc = ensure_image_buffers(e, W, H, nf, need_gray))) return rc;
+    const int channels = image_channels(frames[f0]);
+    if ((rc = ensure_image_buffers(e, W, H, nf, need_gray, channels))) return rc;
     uint64_t q_entries = 0;
     if ((rc = layout_queues(pl, nf, &q_entries))) return rc;
     const size_t n_pass = pl->pass_bounds.size() - 1;
@@ -670,7 +676,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
     if ((rc = stage_frames(e, frames + f0, nf, W, H, &d_gray, &gray_frame_bytes, &gray_stride))) return rc;
 
     HIP_TRY(hipEventRecord(e->ev[0], e->stream));
-    if ((rc = enqueue_integral(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf))) return rc;
+    if ((rc = enqueue_integral(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf, channels))) return rc;
     HIP_TRY(hipEventRecord(e->ev[1], e->stream));
 
     const bool count = (p.flags & VJ_FLAG_COUNTERS) != 0;
@@ -1197,26 +1203,33 @@ int vj_env_reserve(vj_env* e, int max_w, int max_h, int max_batch) {
     return ensure_image_buffers(e, max_w, max_h, max_batch, true);
 }
 
-int vj_integral(vj_env* e, const uint8_t* gray, int w, int h, int stride, uint32_t* sum, uint64_t* sqsum) {
-    if (!e || !gray || !sum || !sqsum || w <= 0 || h <= 0 || stride < w) return VJ_ERR_ARG;
+int vj_integral_image(vj_env* e, const vj_image* image, uint32_t* sum, uint64_t* sqsum) {
+    if (!e || !image || !image->data || !sum || !sqsum) return VJ_ERR_ARG;
+    const int w = image->width, h = image->height, ch = image_channels(*image);
+    if (w <= 0 || h <= 0 || (ch != 1 && ch != 3 && ch != 4) || image->stride < w * ch) return VJ_ERR_ARG;
     if ((uint64_t)(w + 1) * (uint64_t)(h + 3) >= (1ull << 30)) {
         set_error("image too large");
         return VJ_ERR_LIMIT;
     }
     HIP_TRY(hipSetDevice(e->device));
     int rc;
-    if ((rc = ensure_image_buffers(e, w, h, 1, true))) return rc;
-    vj_image im{gray, w, h, stride, 0};
+    if ((rc = ensure_image_buffers(e, w, h, 1, true, ch))) return rc;
     const uint8_t* d_gray;
     size_t fb;
     int gs;
-    if ((rc = stage_frames(e, &im, 1, w, h, &d_gray, &fb, &gs))) return rc;
-    if ((rc = enqueue_integral(e, d_gray, fb, gs, w, h, 1))) return rc;
+    if ((rc = stage_frames(e, image, 1, w, h, &d_gray, &fb, &gs))) return rc;
+    if ((rc = enqueue_integral(e, d_gray, fb, gs, w, h, 1, ch))) return rc;
     const size_t n = (size_t)(w + 1) * (size_t)(h + 1);
     HIP_TRY(hipMemcpyAsync(sum, e->d_sum.p, n * 4, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipMemcpyAsync(sqsum, e->d_sqsum.p, n * 8, hipMemcpyDeviceToHost, e->stream));
     HIP_TRY(hipStreamSynchronize(e->stream));
     return VJ_OK;
+}
+
+int vj_integral(vj_env* e, const uint8_t* gray, int w, int h, int stride, uint32_t* sum, uint64_t* sqsum) {
+    if (!e || !gray || !sum || !sqsum || w <= 0 || h <= 0 || stride < w) return VJ_ERR_ARG;
+    vj_image im{gray, w, h, stride, 0, 1};
+    return vj_integral_image(e, &im, sum, sqsum);
 }
 
 int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames, const vj_params* p,
@@ -1230,9 +1243,15 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
     }
     const int W = frames[0].width, H = frames[0].height;
     if (W <= 0 || H <= 0) return VJ_ERR_ARG;
+    const int CH = image_channels(frames[0]);
+    if (CH != 1 && CH != 3 && CH != 4) {
+        set_error("frames must have 1 (gray), 3 (BGR) or 4 (BGRA) channels");
+        return VJ_ERR_ARG;
+    }
     for (int i = 0; i < n_frames; ++i) {
-        if (!frames[i].data || frames[i].width != W || frames[i].height != H || frames[i].stride < W) {
-            set_error("frame %d: all frames of a batch must be non-null and of equal size", i);
+        if (!frames[i].data || frames[i].width != W || frames[i].height != H || image_channels(frames[i]) != CH ||
+            frames[i].stride < W * CH) {
+            set_error("frame %d: all frames of a batch must be non-null and of equal size and channel count", i);
             return VJ_ERR_ARG;
         }
     }

@@ -98,6 +98,37 @@ __device__ __forceinline__ uint32_t load_px4(const uint8_t* row, uint32_t x, uin
     return v;
 }
 
+// Image ingest: 3-channel BGR / 4-channel BGRA frames are converted on the fly with OpenCV's 8-bit
+// fixed-point BGR2GRAY, (1868 B + 9617 G + 4899 R + 8192) >> 14 (OpenCV 2.4.2 imgproc, the cvCvtColor the
+// reference calls at clif.cpp:328 — third-party arithmetic), fused into both pixel reads
+// of the integral so that no gray copy is written.
+__device__ __forceinline__ uint32_t bgr2gray(uint32_t b, uint32_t g, uint32_t r) {
+    return (b * 1868u + g * 9617u + r * 4899u + 8192u) >> 14;
+}
+__device__ __forceinline__ uint32_t load_gray4(const uint8_t* row, uint32_t x, uint32_t width, uint32_t ch) {
+    if (ch <= 1u) return load_px4(row, x, width);
+    const uint8_t* p = row + (size_t)x * ch;
+    uint32_t v = 0;
+    if (x + 4 <= width && ((uintptr_t)p & 3u) == 0) {
+        const uint32_t* w = reinterpret_cast<const uint32_t*>(p);
+        if (ch == 3u) {   // b0 g0 r0 b1 | g1 r1 b2 g2 | r2 b3 g3 r3
+            const uint32_t w0 = w[0], w1 = w[1], w2 = w[2];
+            v = bgr2gray(w0 & 0xffu, (w0 >> 8) & 0xffu, (w0 >> 16) & 0xffu) |
+                bgr2gray(w0 >> 24, w1 & 0xffu, (w1 >> 8) & 0xffu) << 8 |
+                bgr2gray((w1 >> 16) & 0xffu, w1 >> 24, w2 & 0xffu) << 16 |
+                bgr2gray((w2 >> 8) & 0xffu, (w2 >> 16) & 0xffu, w2 >> 24) << 24;
+        } else {
+#pragma unroll
+            for (int c = 0; c < 4; ++c) v |= bgr2gray(w[c] & 0xffu, (w[c] >> 8) & 0xffu, (w[c] >> 16) & 0xffu) << (8 * c);
+        }
+        return v;
+    }
+#pragma unroll
+    for (int c = 0; c < 4; ++c)
+        if (x + c < width) v |= bgr2gray(p[c * ch], p[c * ch + 1u], p[c * ch + 2u]) << (8 * c);
+    return v;
+}
+
 __global__ __launch_bounds__(256) void band_colsum(IntegralArgs a) {
     const uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 4u;
     const uint32_t band = blockIdx.y, frame = blockIdx.z;
@@ -109,7 +140,7 @@ __global__ __launch_bounds__(256) void band_colsum(IntegralArgs a) {
     for (int r = 0; r < BAND_ROWS; ++r) {
         const uint32_t y = y0 + r;
         if (y < a.height && x < a.width) {
-            const uint32_t v = load_px4(img + (size_t)y * a.gray_stride, x, a.width);
+            const uint32_t v = load_gray4(img + (size_t)y * a.gray_stride, x, a.width, a.channels);
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t p = (v >> (8 * c)) & 0xffu;
@@ -201,7 +232,7 @@ __global__ __launch_bounds__(256) void band_rows(IntegralArgs a) {
         for (int r = 0; r < BAND_ROWS; ++r) {
             const uint32_t y = y0 + r;
             if (y < a.height) {  // uniform
-                const uint32_t v = in ? load_px4(img + (size_t)y * a.gray_stride, x, a.width) : 0u;
+                const uint32_t v = in ? load_gray4(img + (size_t)y * a.gray_stride, x, a.width, a.channels) : 0u;
                 uint32_t ls[4];
                 uint64_t lq[4];
 #pragma unroll

@@ -174,11 +174,17 @@ int vj_integral(vj_env* e, const uint8_t* gray, int w, int h, int stride,
                 uint32_t* sum, uint64_t* sqsum);
 
 /* ----------------------------------------------------------------- detect */
+struct vj_image;
+/* clifGrayscaleIntegral (clif.h:67-70, clif.cpp:326-335): gray conversion + both integrals of one image
+ * (host or device pointer, 1 / 3 / 4 channels); outputs as vj_integral.                       */
+int  vj_integral_image(vj_env* e, const struct vj_image* image, uint32_t* sum, uint64_t* sqsum);
 typedef struct vj_image {
-    const uint8_t* data;       /* 8-bit single channel                          */
+    const uint8_t* data;       /* 8-bit, interleaved channels                   */
     int32_t width, height;
     int32_t stride;            /* bytes per row                                 */
     int32_t on_device;         /* 0: host pointer; 1: device pointer on env's GPU */
+    int32_t channels;          /* 0 or 1: gray (the configs' contract); 3: BGR, 4: BGRA — converted on the
+                                  fly with OpenCV's 8-bit BGR2GRAY, as setupImage does (clif.cpp:326-335) */
 } vj_image;
 
 typedef struct vj_rect {       /* CLODWeightedRect (clod.h:39-42) + provenance  */
@@ -191,7 +197,8 @@ typedef struct vj_rect {       /* CLODWeightedRect (clod.h:39-42) + provenance  
 #define VJ_MAX_STAGES 64
 typedef struct vj_counters {
     uint64_t windows;          /* candidate windows enumerated                  */
-    uint64_t stump_evals;      /* tree-node evaluations                         */
+    uint64_t stump_evals;      /* tree-node evaluations: every node of every stage a window enters (exact for
+                                  stump cascades; an upper bound of the walk's visits for multi-node trees) */
     uint64_t gather_bytes;     /* 48*windows + 16*sum(nrects)   */
     uint64_t stage_entered[VJ_MAX_STAGES]; /* windows entering each stage       */
 } vj_counters;

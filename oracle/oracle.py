@@ -253,6 +253,8 @@ class Oracle:
         L.oc_detect_opencvlike.argtypes = [C.POINTER(_OcCascade), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_OcStats)]
         L.oc_detect_opencvlike.restype = C.c_int
+        L.oc_bgr2gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.oc_bgr2gray.restype = None
         L.oc_group_rectangles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
         L.oc_group_rectangles.restype = C.c_int
 
@@ -333,6 +335,14 @@ class Oracle:
                  "gather_bytes": 48 * int(st.windows) + 16 * int(st.rect_evals),
                  "stage_entered": [int(v) for v in st.stage_entered[:c.n_stages]]}
         return r, stats
+
+    def bgr2gray(self, img: np.ndarray) -> np.ndarray:
+        """(h, w, 3|4) uint8 BGR / BGRA -> (h, w) gray, OpenCV's 8-bit fixed-point formula."""
+        g = np.ascontiguousarray(img)
+        h, w, ch = g.shape
+        out = np.empty((h, w), np.uint8)
+        self.lib.oc_bgr2gray(g.ctypes.data, w, h, g.strides[0], ch, out.ctypes.data, out.strides[0])
+        return out
 
     def detect_opencvlike(self, c: CascadeArrays, gray: np.ndarray, min_size=(0, 0), scale_factor: float = 1.1,
                           cap: int = 1 << 20):

@@ -624,3 +624,17 @@ int oc_detect_opencvlike(const oc_cascade* c, const uint8_t* gray, int W, int H,
     *n_total = found;
     return found < cap ? found : cap;
 }
+
+/* --------------------------------------------------------------- image ingest */
+/* BGR / BGRA -> gray as setupImage gets it from cvCvtColor(CV_BGR2GRAY) (clif.cpp:326-335, :328).  The
+ * arithmetic is OpenCV 2.4.2's 8-bit path (imgproc color.cpp, RGB2Gray<uchar>: coefficients 1868 / 9617 /
+ * 4899 at 14 fractional bits, rounding term 1 << 13) — third-party code that is NOT under /root/reference,
+ * so this is its published formula, parity unpinned; clif.cl:12-15's float formula is a
+ * different, unused kernel.  channels = 3 or 4, interleaved, B first.                                   */
+void oc_bgr2gray(const uint8_t* bgr, int W, int H, int stride, int channels, uint8_t* gray, int gray_stride) {
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x) {
+            const uint8_t* p = bgr + (size_t)y * stride + (size_t)x * channels;
+            gray[(size_t)y * gray_stride + x] = (uint8_t)((p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14);
+        }
+}

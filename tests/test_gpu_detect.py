@@ -61,8 +61,15 @@ def test_detect_matches_live_oracle_large(env, oracle, cascades, casc, kind, h, 
     r = run(env, c, img)
     ro, st = oracle.detect(a, img)
     assert as_list(r.rects) == as_list(ro)
-    assert r.stage_entered == st["stage_entered"] and r.stump_evals == st["stump_evals"]
-    assert r.gather_bytes == st["gather_bytes"] == 48 * st["windows"] + 16 * st["rect_evals"]
+    assert r.stage_entered == st["stage_entered"]
+    if casc == "frontalface_alt2":
+        # multi-node trees: the library prices every node of an entered stage (what the lanes execute), the oracle
+        # the nodes a window's walk visits — an upper bound, exact for stump cascades (include/vj.h: vj_counters)
+        assert r.stump_evals == sum(n * t["n_nodes"] for n, sg in zip(r.stage_entered, c.stages)
+                                    for t in c.trees[sg["first_tree"]:sg["first_tree"] + sg["n_trees"]]) >= st["stump_evals"]
+    else:
+        assert r.stump_evals == st["stump_evals"]
+        assert r.gather_bytes == st["gather_bytes"] == 48 * st["windows"] + 16 * st["rect_evals"]
 
 
 def test_batch_equals_single_frames(env, oracle, cascades):
@@ -364,3 +371,29 @@ def test_native_library_is_the_one_running(env):
     maps = open("/proc/self/maps").read()
     assert "libvjhip.so" in maps
     assert "gfx950" in env.device_name
+
+
+def test_color_frames_detect_like_their_gray(env, oracle, cascades):
+    """Image ingest: BGR / BGRA frames converted inside the integral kernels give exactly the
+    detections of the oracle-converted gray frames — host arrays, strided ROI views and device-resident batches."""
+    import torch
+    c, a = cascades("frontalface_alt")
+    rng = np.random.default_rng(77)
+    gray = [make_frame(k, 40 + i, 300, 420) for i, k in enumerate(("noise", "blocks"))]
+    for ch in (3, 4):
+        # color frames whose gray value is the synthetic frame +- channel noise
+        col = [np.clip(g[..., None].astype(np.int16) + rng.integers(-20, 21, g.shape + (ch,)), 0, 255).astype(np.uint8) for g in gray]
+        want = [oracle.bgr2gray(f) for f in col]
+        base = env.detect(c, want, default_params(flags=VJ_FLAG_COUNTERS))
+        r = env.detect(c, col, default_params(flags=VJ_FLAG_COUNTERS), color=True)
+        assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
+        for f in range(2):
+            ro, _ = oracle.detect(a, want[f])
+            assert as_list(r.rects[r.rects["frame"] == f]) == as_list(ro)
+        t = torch.from_numpy(np.stack(col)).cuda()
+        rd = env.detect(c, DeviceFrames.from_torch(t), default_params(flags=VJ_FLAG_COUNTERS))
+        assert np.array_equal(rd.rects, base.rects)
+        roi = col[0][5:250, 7:333]
+        rr = env.detect(c, roi, default_params(), color=True)
+        rg = env.detect(c, np.ascontiguousarray(want[0][5:250, 7:333]), default_params())
+        assert np.array_equal(rr.rects, rg.rects)

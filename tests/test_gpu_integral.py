@@ -53,3 +53,20 @@ def test_integral_4096_wraps_and_totals(env):
     white = np.full((4200, 4200), 255, np.uint8)   # > 2^32: the sum wraps like CV_32S
     s, q = env.integral(white)
     assert int(s[-1, -1]) == (255 * 4200 * 4200) % (1 << 32) and int(q[-1, -1]) == 255 * 255 * 4200 * 4200
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("h,w,ch", [(1, 1, 3), (7, 5, 4), (33, 130, 3), (64, 257, 4), (480, 641, 3), (720, 1280, 4)])
+def test_color_ingest_integral(env, oracle, h, w, ch):
+    """clifGrayscaleIntegral: BGR / BGRA converted inside the integral kernels == oracle gray -> oracle integral."""
+    rng = np.random.default_rng(h * 1000 + w + ch)
+    img = rng.integers(0, 256, (h, w, ch), dtype=np.uint8)
+    s, q = env.integral(img)
+    so, qo = oracle.integral(oracle.bgr2gray(img))
+    assert np.array_equal(s, so) and np.array_equal(q, qo)
+    # a strided ROI view (rows not 4-byte aligned) takes the byte-load path
+    if h > 8 and w > 8:
+        roi = img[3:h - 2, 1:w - 3]
+        s, q = env.integral(roi)
+        so, qo = oracle.integral(oracle.bgr2gray(roi))
+        assert np.array_equal(s, so) and np.array_equal(q, qo)

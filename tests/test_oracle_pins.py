@@ -122,3 +122,18 @@ def test_opencvlike_baseline_sanity(oracle, cascades):
     # min_size skips whole scales
     r3, st3 = oracle.detect_opencvlike(a, img, min_size=(60, 60))
     assert st3["windows"] < st["windows"] and all(w >= 60 for w in r3["w"])
+
+
+def test_bgr2gray_known_answers(oracle):
+    import numpy as np
+    """OpenCV's 8-bit BGR2GRAY (third-party formula, unpinned by the reference): primaries, white, the rounding
+    term, alpha ignored; cross-checked against numpy integer arithmetic on random pixels."""
+    px = np.array([[[255, 255, 255], [255, 0, 0], [0, 255, 0], [0, 0, 255], [0, 0, 0], [1, 1, 1], [4, 0, 0], [5, 0, 0]]], np.uint8)
+    assert oracle.bgr2gray(px).tolist() == [[255, 29, 150, 76, 0, 1, 0, 1]]     # 4*1868+8192 = 15664 < 16384 <= 5*1868+8192
+    rng = np.random.default_rng(5)
+    img = rng.integers(0, 256, (37, 53, 4), dtype=np.uint8)
+    want = ((img[..., 0].astype(np.uint32) * 1868 + img[..., 1].astype(np.uint32) * 9617 + img[..., 2].astype(np.uint32) * 4899 + 8192) >> 14)
+    assert np.array_equal(oracle.bgr2gray(img), want.astype(np.uint8))
+    assert np.array_equal(oracle.bgr2gray(img[..., :3]), want.astype(np.uint8))
+    g = rng.integers(0, 256, (9, 11), dtype=np.uint8)                          # B = G = R returns the gray value exactly
+    assert np.array_equal(oracle.bgr2gray(np.repeat(g[..., None], 3, 2)), g)
