@@ -132,6 +132,8 @@ _SIGNATURES = {
     "vj_env_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "vj_integral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vj_integral_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vj_detect_rois": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.c_void_p, C.c_int, C.POINTER(Params),
+                                 C.POINTER(_Result)]),
     "vj_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.POINTER(Params),
                             C.POINTER(_Result)]),
     "vj_result_free": (None, [C.POINTER(_Result)]),
@@ -318,11 +320,9 @@ class Environment:
                "vj_integral")
         return s, q
 
-    def detect(self, cascade: Cascade, frames, params: Params | None = None, color: bool = False) -> DetectResult:
-        """frames: 2-D uint8 array, 3-D (n, h, w) array, list of 2-D arrays, or
-        DeviceFrames (frames already resident in HBM).  color=True: every frame is (h, w, 3 | 4) BGR / BGRA
-        (one 3-D array, a 4-D batch or a list) and is converted to gray on the device."""
-        p = params or default_params()
+    @staticmethod
+    def _images(frames, color: bool):
+        """-> (ctypes array of vj_image, n, arrays to keep alive)"""
         keep = []
         if isinstance(frames, DeviceFrames):
             n = frames.n
@@ -330,28 +330,52 @@ class Environment:
             for i in range(n):
                 imgs[i] = _Image(frames.ptr + i * frames.stride * frames.height, frames.width, frames.height,
                                  frames.stride, 1, frames.channels)
-        else:
-            if isinstance(frames, np.ndarray) and frames.ndim == (3 if color else 2):
-                frames = [frames]
-            frames = list(frames)
-            n = len(frames)
-            imgs = (_Image * max(n, 1))()
-            for i, f in enumerate(frames):
-                if color:
-                    if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] not in (3, 4):
-                        raise ValueError("color frames must be (h, w, 3|4) uint8 (BGR / BGRA)")
-                    g = _pixel_contiguous(f)
-                    keep.append(g)
-                    imgs[i] = _Image(g.ctypes.data, g.shape[1], g.shape[0], g.strides[0], 0, g.shape[2])
-                    continue
-                if f.dtype != np.uint8 or f.ndim != 2:
-                    raise ValueError("frames must be 2-D uint8 (8-bit single channel)")
-                g = f if f.strides[1] == 1 else np.ascontiguousarray(f)
+            return imgs, n, keep
+        if isinstance(frames, np.ndarray) and frames.ndim == (3 if color else 2):
+            frames = [frames]
+        frames = list(frames)
+        n = len(frames)
+        imgs = (_Image * max(n, 1))()
+        for i, f in enumerate(frames):
+            if color:
+                if f.dtype != np.uint8 or f.ndim != 3 or f.shape[2] not in (3, 4):
+                    raise ValueError("color frames must be (h, w, 3|4) uint8 (BGR / BGRA)")
+                g = _pixel_contiguous(f)
                 keep.append(g)
-                imgs[i] = _Image(g.ctypes.data, g.shape[1], g.shape[0], g.strides[0], 0, 1)
+                imgs[i] = _Image(g.ctypes.data, g.shape[1], g.shape[0], g.strides[0], 0, g.shape[2])
+                continue
+            if f.dtype != np.uint8 or f.ndim != 2:
+                raise ValueError("frames must be 2-D uint8 (8-bit single channel)")
+            g = f if f.strides[1] == 1 else np.ascontiguousarray(f)
+            keep.append(g)
+            imgs[i] = _Image(g.ctypes.data, g.shape[1], g.shape[0], g.strides[0], 0, 1)
+        return imgs, n, keep
+
+    def detect_rois(self, cascade: Cascade, frames, rois, params: Params | None = None, color: bool = False) -> DetectResult:
+        """vj_detect_rois: `rois` = rows of (frame, x, y, w, h); ROIs of equal size share one batched pass.  In the
+        result rects['frame'] is the ROI's row and x / y are relative to the ROI's origin."""
+        p = params or default_params()
+        imgs, n, keep = self._images(frames, color)
+        r = np.ascontiguousarray(np.asarray(rois, np.int32).reshape(-1, 5))
+        res = _Result()
+        lib = load_library()
+        _check(lib.vj_detect_rois(self._h, cascade._h, imgs, n, r.ctypes.data, len(r), C.byref(p), C.byref(res)),
+               "vj_detect_rois")
+        return self._result(lib, res, cascade)
+
+    def detect(self, cascade: Cascade, frames, params: Params | None = None, color: bool = False) -> DetectResult:
+        """frames: 2-D uint8 array, 3-D (n, h, w) array, list of 2-D arrays, or
+        DeviceFrames (frames already resident in HBM).  color=True: every frame is (h, w, 3 | 4) BGR / BGRA
+        (one 3-D array, a 4-D batch or a list) and is converted to gray on the device."""
+        p = params or default_params()
+        imgs, n, keep = self._images(frames, color)
         res = _Result()
         lib = load_library()
         _check(lib.vj_detect(self._h, cascade._h, imgs, n, C.byref(p), C.byref(res)), "vj_detect")
+        return self._result(lib, res, cascade)
+
+    @staticmethod
+    def _result(lib, res, cascade) -> DetectResult:
         try:
             if res.count:
                 buf = (C.c_char * (RECT_DTYPE.itemsize * res.count)).from_address(res.rects)

@@ -1316,6 +1316,70 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
     return VJ_OK;
 }
 
+// Second cascade on regions of interest (config 5: eyes inside faces).  A ROI is a view —
+// pointer + stride — into its frame, as the reference's callers would pass a sub-image header; detection windows
+// come in few distinct sizes, so the ROIs are grouped by size and every group is ONE batched vj_detect pass.
+int vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames, const vj_roi* rois, int n_rois,
+                   const vj_params* p, vj_result* out) {
+    if (!e || !c || !p || !out || n_frames < 0 || n_rois < 0 || (n_rois > 0 && (!frames || !rois))) return VJ_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    std::map<std::pair<int, int>, std::vector<int>> by_size;   // (w, h) -> ROI indices
+    for (int i = 0; i < n_rois; ++i) {
+        const vj_roi& r = rois[i];
+        if (r.frame < 0 || r.frame >= n_frames || !frames[r.frame].data || r.w <= 0 || r.h <= 0 || r.x < 0 || r.y < 0 ||
+            r.x + r.w > frames[r.frame].width || r.y + r.h > frames[r.frame].height) {
+            set_error("roi %d lies outside its frame", i);
+            return VJ_ERR_ARG;
+        }
+        by_size[{r.w, r.h}].push_back(i);
+    }
+    std::vector<vj_rect> all;
+    for (const auto& kv : by_size) {
+        std::vector<vj_image> views;
+        int ch0 = -1;
+        for (int i : kv.second) {
+            const vj_roi& r = rois[i];
+            const vj_image& f = frames[r.frame];
+            const int ch = image_channels(f);
+            if (ch0 < 0) ch0 = ch;
+            if (ch != ch0) {
+                set_error("ROIs of one size must come from frames with the same channel count");
+                return VJ_ERR_ARG;
+            }
+            views.push_back(vj_image{f.data + (size_t)r.y * (size_t)f.stride + (size_t)r.x * (size_t)ch, r.w, r.h, f.stride,
+                                     f.on_device, f.channels});
+        }
+        vj_result part;
+        int rc = vj_detect(e, c, views.data(), (int)views.size(), p, &part);
+        if (rc) {
+            vj_result_free(&part);
+            return rc;
+        }
+        for (uint32_t k = 0; k < part.count; ++k) {
+            vj_rect rr = part.rects[k];
+            rr.frame = kv.second[(size_t)rr.frame];   // index in the batch -> ROI index
+            all.push_back(rr);
+        }
+        // counters and times add up over the groups
+        out->counters.windows += part.counters.windows;
+        out->counters.stump_evals += part.counters.stump_evals;
+        out->counters.gather_bytes += part.counters.gather_bytes;
+        for (int s2 = 0; s2 < VJ_MAX_STAGES; ++s2) out->counters.stage_entered[s2] += part.counters.stage_entered[s2];
+        out->timing.integral_ms += part.timing.integral_ms;
+        out->timing.cascade_ms += part.timing.cascade_ms;
+        out->timing.total_ms += part.timing.total_ms;
+        vj_result_free(&part);
+    }
+    std::stable_sort(all.begin(), all.end(), [](const vj_rect& a, const vj_rect& b) { return a.frame < b.frame; });
+    out->count = (uint32_t)all.size();
+    if (!all.empty()) {
+        out->rects = (vj_rect*)malloc(all.size() * sizeof(vj_rect));
+        if (!out->rects) return VJ_ERR_NOMEM;
+        memcpy(out->rects, all.data(), all.size() * sizeof(vj_rect));
+    }
+    return VJ_OK;
+}
+
 void vj_result_free(vj_result* r) {
     if (!r) return;
     free(r->rects);

@@ -243,6 +243,14 @@ int  vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fra
                const vj_params* p, vj_result* out);
 void vj_result_free(vj_result* r);
 
+/* A second cascade on regions of interest (BASELINE config 5: haarcascade_eye inside every face;
+ * the reference's caller would hand clodDetectObjects a sub-image header: pointer + widthStep).
+ * ROIs are views into `frames`; ROIs of equal size share one batched pass.  In the result,
+ * rect.frame is the ROI's index and x / y are relative to the ROI's origin.                  */
+typedef struct vj_roi { int32_t frame, x, y, w, h; } vj_roi;
+int  vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames,
+                    const vj_roi* rois, int n_rois, const vj_params* p, vj_result* out);
+
 /* filterResult (clod.cpp:182-357) as cv::groupRectangles defines it (tempcv.cpp:130-243): groups
  * `rects` (sorted by frame; grouped per frame, in place), keeps classes with more than
  * group_threshold members, weight = members, scale_idx = -1.  vj_detect applies it with

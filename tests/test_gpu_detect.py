@@ -17,7 +17,10 @@ DET = {d["id"]: d for d in json.load(open(os.path.join(G, "detect.json")))}
 LINEAR = [c for c in DETECT_CASES if c[1] not in ("frontalface_alt_tree",)]
 
 
-def as_list(rects):
+def as_list(rects, with_frame=False):
+    if with_frame:   # oracle records carry no frame: 0
+        return [(int(r["frame"]) if "frame" in r.dtype.names else 0,) + tuple(int(r[k]) for k in ("scale_idx", "x", "y", "w", "h"))
+                for r in rects]
     return [[int(r[k]) for k in ("scale_idx", "x", "y", "w", "h")] for r in rects]
 
 
@@ -344,6 +347,26 @@ def test_config5_two_cascades_on_rois(env, oracle, cascades):
             assert as_list(eyes.rects) == as_list(eo) and eyes.stage_entered == est["stage_entered"]
             n_rois += 1
     assert len(faces.rects) > 0 and n_rois > 0
+    # the same second leg through vj_detect_rois: every face of every frame in ONE call, ROIs of equal size
+    # batched; host frames, then the device-resident batch
+    import torch
+    rois = np.array([(int(r["frame"]), int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])) for r in faces.rects
+                     if r["w"] >= 30], np.int32)
+    assert len(rois) > 10 and len({(w, h) for _, _, _, w, h in rois.tolist()}) < len(rois)   # sizes repeat
+    pe = default_params(flags=VJ_FLAG_COUNTERS)
+    got = env.detect_rois(ce, frames, rois, pe)
+    want, entered = [], np.zeros(len(got.stage_entered), np.int64)
+    for i, (f, x, y, w, h) in enumerate(rois.tolist()):
+        eo, est = oracle.detect(ae, np.ascontiguousarray(frames[f][y:y + h, x:x + w]))
+        want += [(i,) + t[1:] for t in as_list(eo, with_frame=True)]
+        entered += np.array(est["stage_entered"], np.int64)
+    assert as_list(got.rects, with_frame=True) == want and got.stage_entered == entered.tolist()
+    dev = DeviceFrames.from_torch(torch.from_numpy(frames).cuda())
+    got_d = env.detect_rois(ce, dev, rois, pe)
+    assert np.array_equal(got_d.rects, got.rects)
+    assert env.detect_rois(ce, frames, np.zeros((0, 5), np.int32)).rects.size == 0
+    with pytest.raises(Exception):
+        env.detect_rois(ce, frames, [(0, 1270, 0, 40, 40)])          # outside the frame
 
 
 def test_subbatching_and_detection_buffer_growth(env, cascades):
