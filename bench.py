@@ -245,6 +245,16 @@ def main() -> int:
                       "windows_visited_per_frame": vis // n_cpu,
                       "sample": f"first {n_cpu} frames, {cv_s:.1f} s, oc_detect_opencvlike (restates tempcv.cpp "
                                 f"cvHaarDetectObjects; unpinned, timing only)"}
+        # the OpenCV arithmetic profile on the same frames (vj_detect_opencv: f64 sums, skip rule; one global-gather
+        # kernel, not tuned): what a cvHaarDetectObjects user gets, next to cpu_baseline_opencvlike
+        cv_profile = None
+        if world == 1:
+            env.detect_opencv(casc, dframes)
+            t5 = time.perf_counter()
+            rcv = env.detect_opencv(casc, dframes, flags=VJ_FLAG_COUNTERS)
+            cv_s = time.perf_counter() - t5
+            cv_profile = {"frames_per_s": round(B / cv_s, 1), "ms_per_step": round(cv_s * 1e3, 2),
+                          "windows_visited_per_frame": rcv.windows // B, "detections": len(rcv.rects), "dtype": "f64"}
         out = {
             "metric": "candidate windows/sec, 1080p, haarcascade_frontalface_alt",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -269,7 +279,7 @@ def main() -> int:
             "stump_evals_per_window": round(counted.stump_evals / max(counted.windows, 1), 3),
             "cascade_algorithmic_GBps": round(counted.gather_bytes / (cascade_ms / K * 1e-3) / 1e9, 2),
             "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
-            "cpu_baseline_opencvlike": cpu_cv, "parity_sample_ok": parity,
+            "cpu_baseline_opencvlike": cpu_cv, "opencv_profile": cv_profile, "parity_sample_ok": parity,
         }
     if world > 1:
         dist.barrier()

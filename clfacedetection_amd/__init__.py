@@ -9,5 +9,5 @@ from .api import (  # noqa: F401
     CLOD_BLOCK_IMPLEMENTATION, CLOD_PER_STAGE_ITERATIONS, CLOD_PRECOMPUTE_FEATURES,
     VJ_FLAG_COUNTERS, VJ_FLAG_SIGNED_MEAN, Cascade, DetectResult, DeviceFrames, Environment, Params, VjError,
     clifIntegral, clodDetectObjects, clodInitBuffers, clodInitEnvironment, clodReleaseBuffers,
-    clodReleaseEnvironment, default_params, group_rectangles, load_library,
+    clodReleaseEnvironment, cvHaarDetectObjects, default_params, group_rectangles, load_library,
 )

@@ -70,6 +70,12 @@ class _Image(C.Structure):
                 ("on_device", C.c_int32), ("channels", C.c_int32)]
 
 
+class CvParams(C.Structure):
+    """vj_cv_params: cvHaarDetectObjects' arguments (OpenCV arithmetic profile)."""
+    _fields_ = [("min_w", C.c_int32), ("min_h", C.c_int32), ("scale_factor", C.c_double), ("min_neighbors", C.c_uint32),
+                ("flags", C.c_uint32)]
+
+
 class _Counters(C.Structure):
     _fields_ = [("windows", C.c_uint64), ("stump_evals", C.c_uint64), ("gather_bytes", C.c_uint64),
                 ("stage_entered", C.c_uint64 * VJ_MAX_STAGES)]
@@ -134,6 +140,9 @@ _SIGNATURES = {
     "vj_integral_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "vj_detect_rois": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.c_void_p, C.c_int, C.POINTER(Params),
                                  C.POINTER(_Result)]),
+    "vj_detect_opencv": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.POINTER(CvParams),
+                                   C.POINTER(_Result)]),
+    "vj_cv_params_default": (None, [C.POINTER(CvParams)]),
     "vj_detect": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.POINTER(Params),
                             C.POINTER(_Result)]),
     "vj_result_free": (None, [C.POINTER(_Result)]),
@@ -363,6 +372,17 @@ class Environment:
                "vj_detect_rois")
         return self._result(lib, res, cascade)
 
+    def detect_opencv(self, cascade: Cascade, frames, min_size=(0, 0), scale_factor: float = 1.1, min_neighbors: int = 0,
+                      flags: int = 0, color: bool = False) -> DetectResult:
+        """vj_detect_opencv: cvHaarDetectObjects' scale-cascade path (OpenCV arithmetic profile: f64 sums, threshold
+        bias, ystep = max(2, factor), skip after a stage-0 reject, border rule).  result.windows = visited positions."""
+        imgs, n, keep = self._images(frames, color)
+        p = CvParams(int(min_size[0]), int(min_size[1]), float(scale_factor), int(min_neighbors), int(flags))
+        res = _Result()
+        lib = load_library()
+        _check(lib.vj_detect_opencv(self._h, cascade._h, imgs, n, C.byref(p), C.byref(res)), "vj_detect_opencv")
+        return self._result(lib, res, cascade)
+
     def detect(self, cascade: Cascade, frames, params: Params | None = None, color: bool = False) -> DetectResult:
         """frames: 2-D uint8 array, 3-D (n, h, w) array, list of 2-D arrays, or
         DeviceFrames (frames already resident in HBM).  color=True: every frame is (h, w, 3 | 4) BGR / BGRA
@@ -489,3 +509,13 @@ def clodDetectObjects(image, cascade: Cascade, env: Environment, min_window_size
                        max_w=int(max_window_size[0]), max_h=int(max_window_size[1]),
                        min_neighbors=int(min_neighbors), flags=int(vj_flags))
     return env.detect(cascade, image, p)
+
+
+def cvHaarDetectObjects(image, cascade: Cascade, env: Environment, scale_factor: float = 1.1, min_neighbors: int = 3,
+                        flags: int = 0, min_size=(0, 0), vj_flags: int = 0) -> DetectResult:
+    """The reference demo's OpenCV leg (main.cpp:145: cvHaarDetectObjects(img, cascade, storage, 1.1, ...)) as
+    tempcv.cpp:1188-1456 specifies its scale-cascade path, on the device (OpenCV arithmetic profile).  `flags`
+    must be 0: canny pruning, find-biggest-object and scale-image are other paths."""
+    if flags != 0:
+        raise VjError(4, "cvHaarDetectObjects", "only flags = 0 (the scale-cascade path) is implemented")
+    return env.detect_opencv(cascade, image, min_size, scale_factor, min_neighbors, vj_flags)

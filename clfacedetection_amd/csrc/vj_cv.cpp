@@ -1,0 +1,313 @@
+// Host driver of the OpenCV arithmetic profile: cvHaarDetectObjects' scale-cascade path as the reference
+// keeps it in tempcv.cpp (its private copy of OpenCV 2.4.2 haar.cpp; call site main.cpp:145), on the GPU.
+//   scale loop, window grid            tempcv.cpp:1344-1417
+//   cvSetImagesForHaarClassifierCascade  tempcv.cpp:549-768 (equRect, cvRound-ed rectangles, f32 weights,
+//                                        CV_ADJUST_WEIGHTS = 0; the "align blocks" flags can never be set:
+//                                        kx = r0.width / base_w >= 1)
+//   stage threshold bias               tempcv.cpp:262, 419
+// Linear cascades of stumps or multi-node trees; stage-tree cascades and tilted features are refused.
+// Second arithmetic profile.  OpenCV itself is not available here or on the GPU box, so
+// parity is against the oracle's restatement of the same lines (oc_detect_opencvlike): unpinned.
+#include "vj_env_internal.hpp"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+using namespace vj;
+
+namespace {
+
+inline int cv_round(double v) { return (int)std::lrint(v); }   // cvRound: round half to even
+
+struct CvScaleHost {
+    double factor;
+    int idx;
+    int win_w, win_h, end_x, end_y;
+};
+
+}  // namespace
+
+extern "C" {
+
+void vj_cv_params_default(vj_cv_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->scale_factor = 1.1;
+}
+
+int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames, const vj_cv_params* p,
+                     vj_result* out) {
+    if (!e || !c || !p || !out || n_frames < 0 || (n_frames > 0 && !frames)) return VJ_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    if (n_frames == 0) return VJ_OK;
+    if (!(p->scale_factor > 1.0)) {
+        set_error("scale_factor must be > 1");
+        return VJ_ERR_ARG;
+    }
+    const int W = frames[0].width, H = frames[0].height;
+    if (W <= 0 || H <= 0 || W >= 65535 || H >= 65535) return VJ_ERR_ARG;
+    const int CH = image_channels(frames[0]);
+    for (int i = 0; i < n_frames; ++i)
+        if (!frames[i].data || frames[i].width != W || frames[i].height != H || image_channels(frames[i]) != CH ||
+            (CH != 1 && CH != 3 && CH != 4) || frames[i].stride < W * CH) {
+            set_error("frame %d: all frames of a batch must be non-null and of equal size and channel count", i);
+            return VJ_ERR_ARG;
+        }
+    if ((int)c->stages.size() > VJ_MAX_STAGES || c->stages.empty()) {
+        set_error("cascade has %zu stages; 1..%d are supported", c->stages.size(), VJ_MAX_STAGES);
+        return VJ_ERR_LIMIT;
+    }
+    const StageProgram prog = build_stage_program(*c);
+    bool trees = false;
+    for (size_t s = 0; s < c->stages.size(); ++s) {
+        const int32_t want_pass = s + 1 < c->stages.size() ? (int32_t)(s + 1) : (int32_t)STAGE_ACCEPT;
+        if (prog.on_pass[s] != want_pass || prog.on_fail[s] != STAGE_REJECT) {
+            set_error("the OpenCV profile runs linear cascades only (this one is a stage tree)");
+            return VJ_ERR_UNSUPPORTED;
+        }
+    }
+    for (const auto& t : c->trees)
+        if (t.n_nodes != 1) trees = true;
+    for (const auto& nd : c->nodes)
+        if (nd.tilted) {
+            set_error("tilted features are not supported");
+            return VJ_ERR_UNSUPPORTED;
+        }
+    HIP_TRY(hipSetDevice(e->device));
+
+    // ---- the scale loop (tempcv.cpp:1344-1377)
+    const uint32_t stride = (uint32_t)W + 1u;
+    std::vector<CvScaleHost> hs;
+    {
+        int n_factors = 0;
+        double factor = 1;
+        for (; factor * c->win_w < W - 10 && factor * c->win_h < H - 10; n_factors++, factor *= p->scale_factor) {}
+        factor = 1;
+        for (int k = 0; k < n_factors; ++k, factor *= p->scale_factor) {
+            const double ystep = std::max(2., factor);
+            CvScaleHost s;
+            s.factor = factor;
+            s.idx = k;
+            s.win_w = cv_round(c->win_w * factor);
+            s.win_h = cv_round(c->win_h * factor);
+            s.end_x = cv_round((W - s.win_w) / ystep);
+            s.end_y = cv_round((H - s.win_h) / ystep);
+            if (s.win_w < p->min_w || s.win_h < p->min_h) continue;
+            if (s.end_x <= 0 || s.end_y <= 0) continue;
+            hs.push_back(s);
+        }
+    }
+    const size_t n_nodes = c->nodes.size();
+    std::vector<CvScaleDev> scales(hs.size());
+    std::vector<NodeRec> table(hs.size() * n_nodes);
+    std::vector<UnitDev> rows;
+    bool reach_ok = true;
+    const uint32_t frame_elems = frame_elems_for(W, H);
+    for (size_t k = 0; k < hs.size(); ++k) {
+        uint64_t max_reach = 0;   // furthest element a feature of this scale touches, from the window origin
+        const double scale = hs[k].factor;
+        CvScaleDev& sd = scales[k];
+        memset(&sd, 0, sizeof(sd));
+        sd.ystep = std::max(2., scale);
+        // equRect (tempcv.cpp:607-611): x = y = cvRound(scale), (orig - 2) * scale rounded
+        const int ex = cv_round(scale), ew = cv_round((c->win_w - 2) * scale), eh = cv_round((c->win_h - 2) * scale);
+        const double weight_scale = 1. / (ew * eh);
+        sd.inv_area = weight_scale;
+        sd.win_w = (uint32_t)hs[k].win_w;
+        sd.win_h = (uint32_t)hs[k].win_h;
+        sd.end_x = (uint32_t)hs[k].end_x;
+        sd.end_y = (uint32_t)hs[k].end_y;
+        sd.q0 = (uint32_t)ex * stride + (uint32_t)ex;
+        sd.q1 = sd.q0 + (uint32_t)ew;
+        sd.q2 = (uint32_t)(ex + eh) * stride + (uint32_t)ex;
+        sd.q3 = sd.q2 + (uint32_t)ew;
+        sd.table_first = (uint32_t)(k * n_nodes);
+        sd.scale_idx = (uint32_t)hs[k].idx;
+        NodeRec* recs = table.data() + k * n_nodes;
+        for (size_t t = 0; t < c->trees.size(); ++t) {
+            const vj_tree_desc& td = c->trees[t];
+            for (int j = 0; j < td.n_nodes; ++j) {
+                const vj_node_desc& nd = c->nodes[td.first_node + j];
+                NodeRec& r = recs[td.first_node + j];
+                memset(&r, 0, sizeof(r));
+                if (nd.rect[0].weight == 0.0f || nd.rect[1].weight == 0.0f) {
+                    set_error("node %d: rect 0 and rect 1 must both be weighted", td.first_node + j);
+                    return VJ_ERR_UNSUPPORTED;
+                }
+                double sum0 = 0, area0 = 0;
+                uint32_t dw[3] = {0, 0, 0};
+                for (int q = 0; q < 3; ++q) {
+                    if (nd.rect[q].weight == 0.0f) break;   // hidfeature->rect[k].p0 == 0 ends the list (tempcv.cpp:663)
+                    const int tx = cv_round(nd.rect[q].x * scale), ty = cv_round(nd.rect[q].y * scale);
+                    const int tw = cv_round(nd.rect[q].w * scale), th = cv_round(nd.rect[q].h * scale);
+                    const uint64_t lt = ((uint64_t)ty * stride + (uint64_t)tx) * 4u, dh = (uint64_t)th * stride * 4u;
+                    if (lt > 0xffffffffull || dh > 0xffffffffull || tw * 4 > 32767) {
+                        set_error("feature offsets exceed the device record range");
+                        return VJ_ERR_LIMIT;
+                    }
+                    r.lt[q] = (uint32_t)lt;
+                    r.dh[q] = (uint32_t)dh;
+                    dw[q] = (uint32_t)(tw * 4);
+                    r.w[q] = (float)(nd.rect[q].weight * weight_scale);    // correction_ratio = weight_scale (:731)
+                    if (q == 0)
+                        area0 = tw * th;
+                    else
+                        sum0 += r.w[q] * tw * th;                          // float * int * int, added to a double (:756)
+                    max_reach = std::max<uint64_t>(max_reach, (uint64_t)(ty + th) * stride + (uint64_t)(tx + tw));
+                }
+                r.w[0] = (float)(-sum0 / area0);
+                r.thr = nd.threshold;
+                uint32_t flags = 0;
+                auto leaf_or_node = [&](int v, uint32_t flag, uint32_t* dst) {
+                    if (v > 0) {
+                        flags |= flag;
+                        *dst = (uint32_t)v;
+                    } else {
+                        const float a = c->alpha[td.first_alpha - v];
+                        memcpy(dst, &a, 4);
+                    }
+                };
+                leaf_or_node(nd.left, NODE_LEFT_IS_NODE, &r.left);
+                leaf_or_node(nd.right, NODE_RIGHT_IS_NODE, &r.right);
+                if (j == td.n_nodes - 1) flags |= NODE_TREE_LAST;
+                r.dw01 = dw[0] | (dw[1] << 16);
+                r.dw2_flags = dw[2] | (flags << 16);
+            }
+        }
+        // evaluated windows satisfy x + win_w <= W and y + win_h <= H (border rule); a feature may overshoot its
+        // window by one column / row (separate rounding): the frame allocation has two zeroed slack rows for that
+        const uint64_t origin_max = (uint64_t)(H - hs[k].win_h) * stride + (uint64_t)(W - hs[k].win_w);
+        if (origin_max + max_reach >= (uint64_t)frame_elems) reach_ok = false;
+        for (uint32_t iy = 0; iy < sd.end_y; ++iy) rows.push_back(UnitDev{(uint32_t)k, iy, 0, 0});
+    }
+    std::vector<StageDev> stages(c->stages.size());
+    for (size_t s = 0; s < c->stages.size(); ++s) {
+        memset(&stages[s], 0, sizeof(StageDev));
+        stages[s].first_node = prog.first_node[s];
+        stages[s].n_nodes = prog.n_nodes[s];
+        stages[s].threshold = c->stages[s].threshold - 0.0001f;   // icv_stage_threshold_bias, in f32
+        stages[s].n_trees = (uint32_t)c->stages[s].n_trees;
+    }
+    if (!reach_ok) {
+        set_error("feature reach exceeds the frame allocation");
+        return VJ_ERR_LIMIT;
+    }
+
+    DevBuf d_table, d_scales, d_stages, d_rows, d_det, d_counts;
+    struct Releaser {
+        DevBuf* b[6];
+        ~Releaser() { for (DevBuf* x : b) x->release(); }
+    } releaser{{&d_table, &d_scales, &d_stages, &d_rows, &d_det, &d_counts}};
+    int rc;
+    if ((rc = d_table.ensure(std::max<size_t>(table.size(), 1) * sizeof(NodeRec)))) return rc;
+    if ((rc = d_scales.ensure(std::max<size_t>(scales.size(), 1) * sizeof(CvScaleDev)))) return rc;
+    if ((rc = d_stages.ensure(stages.size() * sizeof(StageDev)))) return rc;
+    if ((rc = d_rows.ensure(std::max<size_t>(rows.size(), 1) * sizeof(UnitDev)))) return rc;
+    const size_t counts_bytes = 2 * VJ_MAX_STAGES * sizeof(uint64_t) + 16;
+    if ((rc = d_counts.ensure(counts_bytes))) return rc;
+    if (!table.empty()) HIP_TRY(hipMemcpy(d_table.p, table.data(), table.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+    if (!scales.empty()) HIP_TRY(hipMemcpy(d_scales.p, scales.data(), scales.size() * sizeof(CvScaleDev), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(d_stages.p, stages.data(), stages.size() * sizeof(StageDev), hipMemcpyHostToDevice));
+    if (!rows.empty()) HIP_TRY(hipMemcpy(d_rows.p, rows.data(), rows.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
+
+    const bool count = (p->flags & VJ_FLAG_COUNTERS) != 0;
+    const uint64_t frame_bytes = (uint64_t)frame_elems * 4u;
+    int max_frames = (int)std::max<uint64_t>(1, std::min<uint64_t>((uint64_t)n_frames, 0xfffffff0ull / frame_bytes));
+    if (e->max_subbatch > 0) max_frames = std::min(max_frames, e->max_subbatch);
+    uint32_t det_cap = 1u << 16;
+    std::vector<vj_rect> all;
+    for (int f0 = 0; f0 < n_frames && !rows.empty(); f0 += max_frames) {
+        const int nf = std::min(max_frames, n_frames - f0);
+        if ((rc = ensure_image_buffers(e, W, H, nf, true, CH))) return rc;
+        const uint8_t* d_gray;
+        size_t gray_frame_bytes;
+        int gray_stride;
+        if ((rc = stage_frames(e, frames + f0, nf, W, H, &d_gray, &gray_frame_bytes, &gray_stride))) return rc;
+        HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+        if ((rc = enqueue_integral(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf, CH))) return rc;
+        HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            if ((rc = d_det.ensure((size_t)det_cap * sizeof(CvDet)))) return rc;
+            HIP_TRY(hipMemsetAsync(d_counts.p, 0, counts_bytes, e->stream));
+            CvArgs a;
+            memset(&a, 0, sizeof(a));
+            a.sum = (const uint32_t*)e->d_sum.p;
+            a.sqsum = (const uint64_t*)e->d_sqsum.p;
+            a.table = (const uint32_t*)d_table.p;
+            a.scales = (const CvScaleDev*)d_scales.p;
+            a.stages = (const StageDev*)d_stages.p;
+            a.rows = (const UnitDev*)d_rows.p;
+            a.n_rows = (uint32_t)rows.size();
+            a.n_frames = (uint32_t)nf;
+            a.n_stages = (uint32_t)stages.size();
+            a.frame_elems = frame_elems;
+            a.stride = stride;
+            a.sum_h = (uint32_t)H + 1u;
+            const int n_blocks = std::max(1, e->n_cu * e->blocks_per_cu);
+            a.total_waves = (uint32_t)n_blocks * CV_WAVES_PER_BLOCK;
+            a.det = (CvDet*)d_det.p;
+            a.det_count = (uint32_t*)((unsigned long long*)d_counts.p + 2 * VJ_MAX_STAGES);
+            a.det_cap = det_cap;
+            a.stage_entered = (unsigned long long*)d_counts.p;
+            HIP_TRY(hipEventRecord(e->ev[2], e->stream));
+            const int hrc = launch_cv_profile_pass(a, trees, count, n_blocks, e->stream);
+            if (hrc) {
+                set_error("cascade launch failed: %s", hipGetErrorString((hipError_t)hrc));
+                return VJ_ERR_HIP;
+            }
+            HIP_TRY(hipEventRecord(e->ev[3], e->stream));
+            std::vector<unsigned long long> h(2 * VJ_MAX_STAGES + 2);
+            HIP_TRY(hipMemcpyAsync(h.data(), d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipStreamSynchronize(e->stream));
+            const uint32_t n_det = (uint32_t)(h[2 * VJ_MAX_STAGES] & 0xffffffffull);
+            if (n_det > det_cap) {   // overflow: grow and redo this sub-batch's cascade
+                while (det_cap < n_det) det_cap *= 2;
+                continue;
+            }
+            float ms_i = 0, ms_c = 0, ms_t = 0;
+            HIP_TRY(hipEventElapsedTime(&ms_i, e->ev[0], e->ev[1]));
+            HIP_TRY(hipEventElapsedTime(&ms_c, e->ev[2], e->ev[3]));
+            HIP_TRY(hipEventElapsedTime(&ms_t, e->ev[0], e->ev[3]));
+            out->timing.integral_ms += ms_i;
+            out->timing.cascade_ms += ms_c;
+            out->timing.total_ms += ms_t;
+            out->timing.n_cascade_launches = 1;
+            if (count) {
+                for (size_t s = 0; s < stages.size(); ++s) out->counters.stage_entered[s] += h[s];
+                out->counters.windows += h[VJ_MAX_STAGES];
+            }
+            std::vector<CvDet> raw(n_det);
+            if (n_det) HIP_TRY(hipMemcpy(raw.data(), d_det.p, (size_t)n_det * sizeof(CvDet), hipMemcpyDeviceToHost));
+            for (const CvDet& d : raw)
+                all.push_back(vj_rect{(int32_t)d.x, (int32_t)d.y, (int32_t)scales[d.slot].win_w, (int32_t)scales[d.slot].win_h,
+                                      0.0f, f0 + (int32_t)d.frame, (int32_t)scales[d.slot].scale_idx});
+            break;
+        }
+    }
+    std::sort(all.begin(), all.end(), [](const vj_rect& a, const vj_rect& b) {
+        return std::tie(a.frame, a.scale_idx, a.y, a.x) < std::tie(b.frame, b.scale_idx, b.y, b.x);
+    });
+    out->count = (uint32_t)all.size();
+    if (!all.empty()) {
+        out->rects = (vj_rect*)malloc(all.size() * sizeof(vj_rect));
+        if (!out->rects) return VJ_ERR_NOMEM;
+        memcpy(out->rects, all.data(), all.size() * sizeof(vj_rect));
+    }
+    if (p->min_neighbors != 0 && out->count) {   // groupRectangles(rectList, max(minNeighbors, 1), GROUP_EPS)
+        rc = vj_group_rectangles(out->rects, &out->count, (int)std::max<uint32_t>(p->min_neighbors, 1u), 0.2);
+        if (rc) return rc;
+    }
+    if (count) {
+        vj_counters& k = out->counters;
+        uint64_t rect_evals = 0;
+        for (size_t s = 0; s < stages.size(); ++s) {
+            k.stump_evals += k.stage_entered[s] * prog.n_nodes[s];
+            rect_evals += k.stage_entered[s] * prog.n_rects[s];
+        }
+        k.gather_bytes = 48ull * k.stage_entered[0] + 16ull * rect_evals;
+    }
+    return VJ_OK;
+}
+
+}  // extern "C"

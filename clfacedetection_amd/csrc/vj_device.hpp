@@ -177,3 +177,52 @@ int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool l
 int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, bool staged, int n_blocks, void* stream);
 
 }  // namespace vj
+
+// ------------------------------------------------------------ OpenCV arithmetic profile (vj_cv.cpp)
+namespace vj {
+
+// One scale of cvHaarDetectObjects' scale-cascade loop (tempcv.cpp:1359-1417) with what
+// cvSetImagesForHaarClassifierCascade (tempcv.cpp:549-632) derives for it.
+struct CvScaleDev {
+    double   ystep;        // max(2, factor)
+    double   inv_area;     // weight_scale = 1 / (equ_w * equ_h)
+    uint32_t win_w, win_h; // cvRound(orig * factor)
+    uint32_t end_x, end_y; // window grid: ix in [0, end_x), iy in [0, end_y)
+    uint32_t q0, q1, q2, q3;   // the four corners of equRect, element offsets from the window origin
+    uint32_t table_first;  // first NodeRec of this scale
+    uint32_t scale_idx;    // index of the factor in the enumeration (skipped scales keep their number)
+    uint32_t pad[6];
+};
+static_assert(sizeof(CvScaleDev) == 80, "CvScaleDev is 80 bytes");
+
+struct CvDet {
+    uint32_t x, y, slot, frame;
+};
+
+constexpr int CV_WAVES_PER_BLOCK = 4;
+constexpr int VJ_MAX_STAGES_DEV = 64;  // == VJ_MAX_STAGES
+constexpr int CV_QCAP = 320;           // survivors of stage 0 a wave collects before it sweeps the later stages
+
+struct CvArgs {
+    const uint32_t* sum;
+    const uint64_t* sqsum;
+    const uint32_t* table;       // NodeRec[] (offsets in bytes, f32 weights per tempcv.cpp:700-768)
+    const CvScaleDev* scales;
+    const StageDev* stages;      // threshold = stage threshold - 0.0001f (tempcv.cpp:262, 419)
+    const UnitDev* rows;         // one unit per (scale, window row): {scale slot, iy}
+    uint32_t n_rows;             // per frame
+    uint32_t n_frames;
+    uint32_t n_stages;
+    uint32_t frame_elems;
+    uint32_t stride;             // W + 1
+    uint32_t sum_h;              // H + 1
+    uint32_t total_waves;
+    CvDet* det;
+    uint32_t* det_count;
+    uint32_t det_cap;
+    unsigned long long* stage_entered;   // [VJ_MAX_STAGES] + [VJ_MAX_STAGES] = windows visited (border ones included)
+};
+
+int launch_cv_profile_pass(const CvArgs& a, bool trees, bool count, int n_blocks, void* stream);
+
+}  // namespace vj

@@ -18,124 +18,9 @@
 #include <memory>
 #include <tuple>
 
-namespace vj {
-
-#define HIP_TRY(expr)                                                                        \
-    do {                                                                                     \
-        hipError_t e_ = (expr);                                                              \
-        if (e_ != hipSuccess) {                                                              \
-            set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
-            return VJ_ERR_HIP;                                                               \
-        }                                                                                    \
-    } while (0)
-
-struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
-    int ensure(size_t bytes) {
-        if (bytes <= cap) return VJ_OK;
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-        // grow geometrically so alternating sizes do not reallocate every call
-        size_t want = std::max(bytes, (size_t)256);
-        hipError_t e = hipMalloc(&p, want);
-        if (e != hipSuccess) {
-            set_error("hipMalloc(%zu) failed: %s", want, hipGetErrorString(e));
-            p = nullptr;
-            return e == hipErrorOutOfMemory ? VJ_ERR_NOMEM : VJ_ERR_HIP;
-        }
-        cap = want;
-        return VJ_OK;
-    }
-    void release() {
-        if (p) (void)hipFree(p);
-        p = nullptr;
-        cap = 0;
-    }
-};
-
-// Everything that depends on (cascade, W, H, params) but not on pixel data.
-struct Plan {
-    std::vector<vj_scale_info> scales_all;   // every enumerated scale
-    std::vector<ScaleDev> scales;            // accepted scales with nwin > 0
-    std::vector<vj_scale_info> scales_info;  // same order as `scales`
-    std::vector<StageDev> stages;
-    std::vector<UnitDev> units;              // first-pass units of one frame (global-gather scales)
-    std::vector<UnitDev> tile_units;         // first-pass tiles of one frame, grouped by LDS class
-    uint32_t class_first[TILE_CLASSES + 1] = {};  // tile_units range of each class
-    uint32_t class_lds[TILE_CLASSES] = {};        // dynamic LDS bytes of each class launch
-    uint32_t block_first = 0, n_block_units = 0;  // tile_units range of the unstaged 2-D blocks (global-gather scales)
-    uint32_t block_lds = 0;
-    uint32_t tile_end = 0;                        // stage at which the tile launches stop
-    bool tree2 = false;                           // every tree: two nodes, node 1 the only node child of node 0
-    uint32_t sp_pad = 0;                          // LDS pitch of the stump-parallel stage table (0 = off)
-    std::vector<uint32_t> pass_bounds;       // stage indices: pass p runs [b[p], b[p+1])
-    uint64_t windows_per_frame = 0;
-    uint32_t frame_elems = 0;
-    uint32_t max_reach_elems = 0;  // furthest element a window origin + feature corner touches
-    bool trees = false;    // some tree has more than one node
-    bool general = false;  // stage tree (not a linear chain of stages)
-    uint32_t n_order = 0;  // stages reachable from stage 0, in StageDev::order
-    StageProgram prog;
-    // device copies
-    DevBuf d_table, d_scales, d_stages, d_units, d_tile_units, d_sp_blocks;
-    uint32_t n_sp_blocks = 0;
-    int frames_q = 0;  // frames the ScaleDev.q_base/q_cap currently describe
-};
-
-}  // namespace vj
+#include "vj_env_internal.hpp"
 
 using namespace vj;
-
-struct vj_env {
-    int device = 0;
-    hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t pass_ev[VJ_MAX_PASSES + 1] = {};
-    hipEvent_t launch_ev[2 * VJ_MAX_LAUNCHES] = {};   // start/stop per launch
-    hipEvent_t fork_ev = nullptr, join_ev = nullptr;
-    hipStream_t stream2 = nullptr;   // second chain of the first part of the cascade
-    int max_subbatch = 0;      // > 0: cap on frames per sub-batch (tests)
-    uint32_t det_cap_init = 1u << 16;  // initial capacity of the detection buffer (grows on overflow)
-    int concurrent = 1;   // 1: the tile chain and the global-gather chain overlap on two streams
-    int concurrent_blocks_per_cu = 1;   // workgroups per CU of the global-gather chain while it overlaps
-    float tile_split = 0.5f;            // scales' worth of tile work handed to the global-gather chain (largest tile scales first)
-    int grid_block_w = 32;              // width of the 2-D window blocks of the global-gather first pass (0: row runs)
-    int global_blocks = 0;              // 1: large scales run as unstaged 2-D blocks in the tile kernel (stump cascades): 2.2x
-                                        // faster than grid + queue passes on its own, but it overlaps the tile chain badly
-    int tile_lds_reserve_kb = 18;       // LDS per CU the tile classes leave to the other chain
-    char name[256] = "";
-    int n_cu = 0;
-    // image buffers
-    DevBuf d_gray, d_sum, d_sqsum, d_band_sum, d_band_sq, d_band_sqp;
-    int slack_w = 0, slack_h = 0, slack_frames = 0;   // layout whose slack rows are known to be zero
-    void *slack_sum = nullptr, *slack_sq = nullptr;
-    // survivor queues + counters + detections
-    DevBuf d_q[MAX_PASSES], d_counts, d_det;   // d_q[p]: windows waiting to enter pass p (p >= 1)
-    uint32_t det_cap = 0;
-    void* h_pinned = nullptr;  // small pinned staging for counts
-    size_t h_pinned_bytes = 0;
-    typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t> PlanKey;
-    std::map<PlanKey, std::unique_ptr<Plan>> plans;
-    // tunables (env vars, read once)
-    int blocks_per_cu = 8;
-    int tile_class_kb[TILE_CLASSES] = {-2, -1, 0};  // image-tile LDS budget per class in KiB; -k = what lets k
-                                                     // workgroups share a CU's 160 KiB; all 0 disables the tile path
-    int tile_min_windows = 768;   // a class is acceptable for a scale when a tile holds at least this many windows
-    int tile_max_dwords_per_window = 600;  // staging a tile must stay far cheaper than gathering its windows from L2
-    int tile_accept_windows = 768;  // scales whose best tile holds fewer windows stay on the global-gather path
-    int tile_end = 64;            // tile launches never enter a pass that begins at or beyond this stage
-    int tile_min_lanes = 0;       // a tile leaves at a pass boundary when fewer windows than this survive in it
-    unsigned long long tile_repack_mask = ~3ull;  // stages (2 and later) before which a tile re-packs its survivors
-    int tile_sp_begin = 3;        // first stage at which a tile may switch to the stump-parallel finish (>= 64: never)
-    int tile_sp_max = 192;
-    int tile_finish = 1;          // 0: stump-parallel finish, 1: wave-split finish
-    int tile_ws_max = 512;
-    int tile_ws_min = 48;         // ... below this many the stump-parallel finish takes over        // windows a tile may carry into the wave-split finish
-    int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales        // ... once at most this many of its windows survive
-    std::vector<int> split_override;
-};
 
 namespace vj {
 
@@ -148,7 +33,7 @@ static uint32_t f2u(float f) {
 static constexpr uint32_t kSlackRows = 2;  // zero rows after row H (defined reads for the
                                            // one-column feature overshoot)
 
-static uint32_t frame_elems_for(int W, int H) {
+uint32_t frame_elems_for(int W, int H) {
     uint64_t e = (uint64_t)(W + 1) * (uint64_t)(H + 1 + kSlackRows);
     e = (e + 63u) & ~(uint64_t)63u;  // keep every frame 256-byte aligned
     return (uint32_t)e;
@@ -298,7 +183,6 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         pl->max_reach_elems = std::max(pl->max_reach_elems, reach);
         pl->windows_per_frame += sd.nwin;
         sd.ny = (uint32_t)si.ny;
-        const uint32_t slot = (uint32_t)pl->scales.size();
 
         // LDS-tile path: does a 64 x (TILE_WAVES * rw) window tile's footprint fit the budget?
         uint32_t reach_x = (uint32_t)(si.equ_x + si.equ_w), reach_y = (uint32_t)(si.equ_y + si.equ_h);
@@ -535,7 +419,7 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
     return VJ_OK;
 }
 
-static int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_gray, int channels = 1) {
+int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_gray, int channels) {
     const size_t fe = frame_elems_for(W, H);
     const uint32_t n_bands = ((uint32_t)H + BAND_ROWS - 1) / BAND_ROWS;
     const uint32_t band_pitch = ((uint32_t)W + 3u) & ~3u;
@@ -557,8 +441,8 @@ static int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_g
 }
 
 // Enqueue the three integral kernels for `frames` frames already on the device.
-static int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int stride, int W, int H, int frames,
-                            int channels = 1) {
+int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int stride, int W, int H, int frames,
+                     int channels) {
     IntegralArgs ia;
     memset(&ia, 0, sizeof(ia));
     ia.channels = (uint32_t)channels;
@@ -604,10 +488,10 @@ static int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes
 
 // Upload host frames (or gather strided device frames) into d_gray with a 4-byte
 // aligned pitch.  Returns the device pointer / pitch the integral kernels should use.
-static inline int image_channels(const vj_image& im) { return im.channels <= 1 ? 1 : im.channels; }
+int image_channels(const vj_image& im) { return im.channels <= 1 ? 1 : im.channels; }
 
-static int stage_frames(vj_env* e, const vj_image* frames, int n, int W, int H, const uint8_t** d_ptr,
-                        size_t* frame_bytes, int* stride) {
+int stage_frames(vj_env* e, const vj_image* frames, int n, int W, int H, const uint8_t** d_ptr, size_t* frame_bytes,
+                 int* stride) {
     const size_t row_bytes = (size_t)W * (size_t)image_channels(frames[0]);
     bool all_dev = true, contiguous = true;
     for (int i = 0; i < n; ++i) {

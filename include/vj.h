@@ -243,6 +243,24 @@ int  vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fra
                const vj_params* p, vj_result* out);
 void vj_result_free(vj_result* r);
 
+/* ------------------------------------------------ OpenCV arithmetic profile */
+/* cvHaarDetectObjects(image, cascade, storage, scale_factor, min_neighbors, flags = 0, min_size)
+ * (call site main.cpp:145; scale-cascade path as tempcv.cpp:1188-1456 keeps it): f64 variance,
+ * node and stage sums, stage threshold - 0.0001f, cvRound-ed rectangles and grid, ystep =
+ * max(2, factor), the skip after a stage-0 reject, the window-touches-border rule.  Raw
+ * candidates (min_neighbors = 0) or cv::groupRectangles.  Linear cascades only.
+ * counters.windows = positions the sequential walk visits.  Parity: against the oracle's
+ * restatement of the same lines — OpenCV itself cannot be run here (unpinned).              */
+typedef struct vj_cv_params {
+    int32_t  min_w, min_h;     /* minSize (0 = none)                              */
+    double   scale_factor;     /* 1.1                                             */
+    uint32_t min_neighbors;
+    uint32_t flags;            /* VJ_FLAG_COUNTERS                                */
+} vj_cv_params;
+void vj_cv_params_default(vj_cv_params* p);
+int  vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames,
+                      const vj_cv_params* p, vj_result* out);
+
 /* A second cascade on regions of interest (BASELINE config 5: haarcascade_eye inside every face;
  * the reference's caller would hand clodDetectObjects a sub-image header: pointer + widthStep).
  * ROIs are views into `frames`; ROIs of equal size share one batched pass.  In the result,

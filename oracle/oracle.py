@@ -356,7 +356,8 @@ class Oracle:
         st = _OcStats()
         n = self.lib.oc_detect_opencvlike(C.byref(s), g.ctypes.data, w, h, g.strides[0], min_size[0], min_size[1],
                                           float(scale_factor), out.ctypes.data, cap, C.byref(n_total), C.byref(st))
-        return out[:n], {"windows": int(st.windows), "stump_evals": int(st.stump_evals)}
+        return out[:n], {"windows": int(st.windows), "stump_evals": int(st.stump_evals),
+                         "stage_entered": [int(v) for v in st.stage_entered[:c.n_stages]]}
 
     # f1 (next row): grouping
     def group_rectangles(self, xywh: np.ndarray, group_threshold: int, eps: float = 0.2):
