@@ -800,6 +800,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             }
             tm->n_launches = (int32_t)linfo.size();
         }
+#ifdef VJ_STAMPS
         if (getenv("VJ_DEBUG_STAMPS")) {  // diagnostic build (-DVJ_STAMPS=1): phase cycle sums of the tile kernel
             const unsigned long long* se =
                 (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * MAX_SCALES + 2);
@@ -811,6 +812,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             }
             fprintf(stderr, "\n");
         }
+#endif
         if (count) {
             const unsigned long long* se =
                 (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * MAX_SCALES + 2);
