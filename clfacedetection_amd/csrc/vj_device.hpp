@@ -119,6 +119,7 @@ struct CascadeArgs {
     uint32_t stride;            // elements per image row (W + 1)
     uint32_t stage_begin, stage_end;  // stages [begin, end) evaluated by this pass
     uint32_t total_waves;       // gridDim.x * WAVES_PER_BLOCK
+    uint32_t xcd_affinity;      // grid pass: waves of one XCD share a contiguous part of the (frame, unit) list
     const QEntry*   q_in;       // survivor queue read by this pass (passes > 0)
     const uint32_t* q_in_count; // per-scale entry counts of q_in
     QEntry*   q_out;            // survivor queue written by this pass (not the last)

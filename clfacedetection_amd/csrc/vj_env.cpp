@@ -605,6 +605,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.sp_blocks = (const SpBlock*)pl->d_sp_blocks.p;
         ca.n_sp_blocks = pl->n_sp_blocks;
         ca.tile_sp_max = (uint32_t)std::min(e->tile_sp_max, (int)TILE_SP_MAX_WINDOWS);
+        ca.xcd_affinity = (uint32_t)e->xcd_affinity;
         ca.tile_finish = (uint32_t)e->tile_finish;
         ca.tile_ws_min = pl->sp_pad != 0u ? (uint32_t)e->tile_ws_min : 0u;   // no stump-parallel tables: wave-split to the end
         ca.tile_ws_max = (uint32_t)std::min(e->tile_ws_max, (int)TILE_WS_MAX_WINDOWS);
@@ -1033,6 +1034,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         e->tile_split = std::max(0.0f, (float)atof(value));
         HIP_TRY(hipStreamSynchronize(e->stream));
         drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "xcd_affinity") == 0) {
+        e->xcd_affinity = atoi(value) != 0;
         return VJ_OK;
     }
     if (strcmp(key, "grid_block_w") == 0) {

@@ -94,6 +94,7 @@ struct vj_env {
     int concurrent = 1;   // 1: the tile chain and the global-gather chain overlap on two streams
     int concurrent_blocks_per_cu = 1;   // workgroups per CU of the global-gather chain while it overlaps
     float tile_split = 0.5f;            // scales' worth of tile work handed to the global-gather chain (largest tile scales first)
+    int xcd_affinity = 1;               // global-gather first pass: one contiguous part of the work per XCD (L2 locality)
     int grid_block_w = 32;              // width of the 2-D window blocks of the global-gather first pass (0: row runs)
     int global_blocks = 0;              // 1: large scales run as unstaged 2-D blocks in the tile kernel (stump cascades): 2.2x
                                         // faster than grid + queue passes on its own, but it overlaps the tile chain badly

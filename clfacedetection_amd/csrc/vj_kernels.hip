@@ -643,7 +643,18 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
         kptr<UnitDev> units = as_k(a.units);
         const uint32_t total_units = a.n_units * a.n_frames;
         const uint32_t frame_bytes4 = a.frame_elems * 4u;
-        for (uint32_t u = rank; u < total_units; u += a.total_waves) {
+        // Blocks are dealt round-robin over the 8 XCDs (observed placement; used for speed only): the waves that
+        // share an XCD — and its 4 MiB L2 — take one contiguous eighth of the (frame, unit) list, i.e. they work on
+        // the same frame's sum image at the same time instead of on every frame in flight.
+        uint32_t u_begin = 0, u_end = total_units, u_step = a.total_waves, u_first = rank;
+        if (a.xcd_affinity != 0u && gridDim.x >= 8u) {
+            const uint32_t xcd = blockIdx.x & 7u;
+            u_begin = (uint32_t)((unsigned long long)total_units * xcd / 8u);
+            u_end = (uint32_t)((unsigned long long)total_units * (xcd + 1u) / 8u);
+            u_step = ((gridDim.x - xcd + 7u) >> 3) * WAVES_PER_BLOCK;
+            u_first = u_begin + (blockIdx.x >> 3) * WAVES_PER_BLOCK + wib;
+        }
+        for (uint32_t u = u_first; u < u_end; u += u_step) {
             const uint32_t frame = u / a.n_units;
             const uint32_t r = u - frame * a.n_units;
             const uint32_t slot = units[r].scale;

@@ -333,3 +333,32 @@ if "configs" in what:
         rc = env.detect(cc, dd, default_params(flags=VJ_FLAG_COUNTERS))
         print(f"{name}: {nb} frames wall {wall:.2f} ms -> {rc.windows/wall/1e6:.2f} Gwin/s, {rc.stump_evals/max(rc.windows,1):.1f} evals/win, {rc.stump_evals/wall/1e6:.1f} Gevals/s, dets {len(r.rects)} " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
         del tt, dd
+if "xcd" in what:
+    base = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+    def show(tag):
+        env.detect(c, df, default_params())
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(c, df, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        rc = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+        ok = np.array_equal(rc.rects, base.rects) and rc.stage_entered == base.stage_entered
+        print(f"{tag}: same={ok} wall {wall:.2f} ms cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    for conc in (0, 1):
+        env.configure("concurrent", conc)
+        for xa in (0, 1):
+            env.configure("xcd_affinity", xa); show(f"concurrent={conc} xcd_affinity={xa}")
+    env.configure("xcd_affinity", 1)
+if "split3" in what:
+    base = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+    def show(tag):
+        env.detect(c, df, default_params())
+        t0 = time.perf_counter(); n = 3
+        for _ in range(n): r = env.detect(c, df, default_params())
+        wall = (time.perf_counter() - t0) / n * 1e3
+        print(f"{tag}: wall {wall:.2f} ms cascade {r.cascade_ms:.2f} ms " + " ".join(f"{l['kind'][0]}{l['lds_class']}:{len(l['scales'])}sc:{l['ms']:.1f}" for l in r.launches), flush=True)
+    for sp in (0.5, 0.75, 1.0, 1.25, 1.5):
+        env.configure("tile_split", sp); show(f"tile_split={sp}")
+    env.configure("tile_split", 0.5)
+    for bw in (16, 24, 32, 48):
+        env.configure("grid_block_w", bw); show(f"grid_block_w={bw}")
+    env.configure("grid_block_w", 32)
