@@ -111,7 +111,7 @@ struct CascadeArgs {
     const UnitDev*  tile_units; // first-pass tiles of ONE frame (LDS-tile scales): first = ix0 | iy0 << 16
     uint32_t n_tile_units;
     uint32_t tile_lds_bytes;    // dynamic LDS of the tile kernel
-    uint32_t* tile_ticket;      // next tile index - gridDim.x of this tile launch (zeroed before the launch)
+    uint32_t* tile_ticket;      // eight ticket counters of this tile launch, one per part of the tile list (zeroed before the launch)
     uint32_t n_frames;
     uint32_t n_scales;
     uint32_t frame_elems;       // elements per frame in sum / sqsum

@@ -680,7 +680,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 ta.tile_units = (const UnitDev*)pl->d_tile_units.p + pl->class_first[cls];
                 ta.n_tile_units = n_cls;
                 ta.tile_lds_bytes = pl->class_lds[cls];
-                ta.tile_ticket = d_qcount[0] + (MAX_SCALES - 1 - cls);   // queue 0 does not exist: its counters are free
+                ta.tile_ticket = d_qcount[0] + (MAX_SCALES - 8u * (cls + 1u));   // queue 0 does not exist: its counters are free
                 // workgroups per CU: what the LDS allows (160 KiB per CU), at most 4 x 8 waves
                 const int per_cu = std::max(1, std::min(32 / TILE_WAVES, (int)(160u * 1024u / ta.tile_lds_bytes)));
                 const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
@@ -702,7 +702,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 ta.tile_units = (const UnitDev*)pl->d_tile_units.p + pl->block_first;
                 ta.n_tile_units = pl->n_block_units;
                 ta.tile_lds_bytes = pl->block_lds;
-                ta.tile_ticket = d_qcount[0] + (MAX_SCALES - 1 - TILE_CLASSES);
+                ta.tile_ticket = d_qcount[0] + (MAX_SCALES - 8u * (TILE_CLASSES + 1u));
                 const int per_cu = two_streams ? e->concurrent_blocks_per_cu : 2;
                 const int tb = (int)std::min<uint64_t>((uint64_t)pl->n_block_units * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
                 const uint32_t deepest = std::min<uint32_t>((uint32_t)pl->stages.size(), handover);

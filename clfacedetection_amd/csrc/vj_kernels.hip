@@ -1195,13 +1195,38 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
 
 #define STAMP(ph) do { if (VJ_STAMPS && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(a.stage_entered + 40 + (ph), t_ - t_last); t_last = t_; } } while (0)
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
-    // Tiles are handed out dynamically (first one = blockIdx.x, then tickets from a global counter): a
-    // workgroup that becomes resident late — e.g. because another kernel holds part of the CU — simply
-    // finds fewer tickets left.  The ticket for the next tile is drawn while this one is processed.
-    uint32_t u = blockIdx.x;
+    // Tiles are handed out dynamically: a workgroup that becomes resident late — e.g. because another kernel
+    // holds part of the CU — simply finds fewer tickets left.  The (frame, tile) list is cut into eight
+    // contiguous parts, one per XCD (blocks b and b + 8 share an XCD under the observed round-robin placement;
+    // speed only): the workgroups of an XCD stage neighbouring tiles of the same frame at the same time, so the
+    // halo rows and the squared-sum corners they share are L2 hits.  Each part has its own ticket counter (one
+    // counter would also be a hot spot for 512 pullers); a workgroup whose part is used up steals from the
+    // others.  The next ticket is drawn while the current tile is processed.
+    const uint32_t my_xcd = blockIdx.x & 7u;
+    auto part_begin = [&](uint32_t x) { return (uint32_t)((unsigned long long)total_units * x / 8u); };
+    auto seeds = [&](uint32_t x) { return gridDim.x > x ? (gridDim.x - x + 7u) >> 3 : 0u; };   // blocks on "XCD" x
+    uint32_t cur_part = my_xcd;
+    auto draw = [&]() -> uint32_t {   // thread 0 only
+        for (uint32_t tries = 0; tries < 8u; ++tries) {
+            const uint32_t x = (cur_part + tries) & 7u;
+            const uint32_t t = atomicAdd(a.tile_ticket + x, 1u);
+            const uint32_t cand = part_begin(x) + seeds(x) + t;
+            if (cand < part_begin(x + 1u)) {
+                cur_part = x;
+                return cand;
+            }
+        }
+        return total_units;
+    };
+    uint32_t u = part_begin(my_xcd) + (blockIdx.x >> 3);
+    if (u >= part_begin(my_xcd + 1u)) {   // more workgroups than tiles in this part: start by stealing
+        if (threadIdx.x == 0) lds_cnt[TILE_WAVES + 8] = draw();
+        __syncthreads();
+        u = __builtin_amdgcn_readfirstlane(lds_cnt[TILE_WAVES + 8]);
+    }
     while (u < total_units) {
         uint32_t next_u = 0;
-        if (threadIdx.x == 0) next_u = gridDim.x + atomicAdd(a.tile_ticket, 1u);
+        if (threadIdx.x == 0) next_u = draw();
         const uint32_t frame = u / a.n_tile_units;
         const uint32_t r = u - frame * a.n_tile_units;
         const uint32_t slot = units[r].scale;
