@@ -17,7 +17,7 @@ struct ScaleDev {
     float    area;         // (float)scaled_window_area
     uint32_t table_first;  // first NodeRec of this scale in the table (image-stride offsets)
     uint32_t q_base;       // first entry of this scale's segment in the survivor queues
-    uint32_t q_cap;        // capacity of that segment (= nwin * frames in flight)
+    uint32_t q_cap;        // capacity of ONE of the segment's Q_PARTS parts (= nwin * frames per part)
     uint32_t scale_idx;    // k of s_k (for the detection record)
     uint32_t ny;           // window grid rows
     // LDS-tile path (tile_rw == 0: this scale runs on the global-gather path)
@@ -89,6 +89,7 @@ constexpr int UNIT_WINDOWS = 512;   // windows per wave-unit == per-wave LDS que
 constexpr int WAVES_PER_BLOCK = 4;
 constexpr int MAX_SCALES = 128;
 constexpr int MAX_PASSES = 8;         // == VJ_MAX_PASSES
+constexpr uint32_t Q_PARTS = 8;       // parts of a scale's survivor-queue segment, by frame group (one per XCD to drain)
 constexpr int TILE_WAVES = 8;        // waves per workgroup of the LDS-tile kernel (16 measured slower)
 constexpr int TILE_W = 64;           // windows per tile row (= lanes of a wave)
 constexpr int TILE_WAVE_CAP = 256;    // windows (= LDS queue entries) per wave of the tile kernel
@@ -121,7 +122,8 @@ struct CascadeArgs {
     uint32_t total_waves;       // gridDim.x * WAVES_PER_BLOCK
     uint32_t xcd_affinity;      // grid pass: waves of one XCD share a contiguous part of the (frame, unit) list
     const QEntry*   q_in;       // survivor queue read by this pass (passes > 0)
-    const uint32_t* q_in_count; // per-scale entry counts of q_in
+    const uint32_t* q_in_count; // entry counts of q_in, [scale][Q_PARTS]
+    uint32_t* q_ticket;         // Q_PARTS chunk-ticket counters of this queue pass (zeroed before the launch)
     QEntry*   q_out;            // survivor queue written by this pass (not the last)
     uint32_t* q_out_count;
     // Tile launches: one survivor queue per pass boundary.  A wave sweeps the cascade one

@@ -376,11 +376,14 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
 
 // (Re)lay out the per-scale queue segments for `frames` frames in flight.
 static int layout_queues(Plan* pl, int frames, uint64_t* total_entries) {
+    // a scale's segment: Q_PARTS parts, part x takes the windows of frames with frame * Q_PARTS / frames == x
+    // (frame itself when frames < Q_PARTS), i.e. at most ceil(frames / Q_PARTS) frames
+    const uint64_t frames_per_part = frames >= (int)Q_PARTS ? ((uint64_t)frames + Q_PARTS - 1) / Q_PARTS : 1;
     uint64_t base = 0;
     for (ScaleDev& sd : pl->scales) {
         sd.q_base = (uint32_t)base;
-        sd.q_cap = sd.nwin * (uint32_t)frames;
-        base += (uint64_t)sd.nwin * (uint64_t)frames;
+        sd.q_cap = (uint32_t)((uint64_t)sd.nwin * frames_per_part);
+        base += (uint64_t)sd.nwin * frames_per_part * Q_PARTS;
     }
     *total_entries = base;
     if (base > 0xffffffffull) {
@@ -542,17 +545,18 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
     // counters block: [MAX_PASSES][MAX_SCALES] queue counts | det_count | pad | one stage_entered[VJ_MAX_STAGES]
     // (u64) array per kernel launch (array 0 is spare)
     const size_t counts_bytes =
-        (MAX_PASSES * MAX_SCALES + 2) * sizeof(uint32_t) + (size_t)(1 + VJ_MAX_LAUNCHES) * VJ_MAX_STAGES * sizeof(uint64_t);
+        (MAX_PASSES * MAX_SCALES * Q_PARTS + 2) * sizeof(uint32_t) + (size_t)(1 + VJ_MAX_LAUNCHES) * VJ_MAX_STAGES * sizeof(uint64_t);
     if ((rc = e->d_counts.ensure(counts_bytes))) return rc;
     if (e->det_cap == 0) {
         e->det_cap = e->det_cap_init;
         if ((rc = e->d_det.ensure((size_t)e->det_cap * sizeof(DetEntry)))) return rc;
     }
     uint32_t* d_qcount[MAX_PASSES];
-    for (int ps = 0; ps < MAX_PASSES; ++ps) d_qcount[ps] = (uint32_t*)e->d_counts.p + ps * MAX_SCALES;
-    uint32_t* d_det_count = (uint32_t*)e->d_counts.p + MAX_PASSES * MAX_SCALES;
+    const size_t q_counts = (size_t)MAX_SCALES * Q_PARTS;   // counters of one queue: [scale][part]
+    for (int ps = 0; ps < MAX_PASSES; ++ps) d_qcount[ps] = (uint32_t*)e->d_counts.p + ps * q_counts;
+    uint32_t* d_det_count = (uint32_t*)e->d_counts.p + MAX_PASSES * q_counts;
     unsigned long long* d_stage_entered =
-        (unsigned long long*)((uint32_t*)e->d_counts.p + MAX_PASSES * MAX_SCALES + 2);
+        (unsigned long long*)((uint32_t*)e->d_counts.p + MAX_PASSES * q_counts + 2);
 
     const uint8_t* d_gray;
     size_t gray_frame_bytes;
@@ -647,6 +651,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             // and appends its survivors to queue ps+1
             qa.q_in = (const QEntry*)e->d_q[ps].p;
             qa.q_in_count = d_qcount[ps];
+            qa.q_ticket = d_qcount[0] + ps * Q_PARTS;   // queue 0 does not exist: its counters serve as tickets
             qa.q_out = last ? nullptr : (QEntry*)e->d_q[ps + 1].p;
             qa.q_out_count = last ? nullptr : d_qcount[ps + 1];
             return qa;
@@ -680,7 +685,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 ta.tile_units = (const UnitDev*)pl->d_tile_units.p + pl->class_first[cls];
                 ta.n_tile_units = n_cls;
                 ta.tile_lds_bytes = pl->class_lds[cls];
-                ta.tile_ticket = d_qcount[0] + (MAX_SCALES - 8u * (cls + 1u));   // queue 0 does not exist: its counters are free
+                ta.tile_ticket = d_qcount[0] + (q_counts - 8u * (cls + 1u));   // queue 0 does not exist: its counters are free
                 // workgroups per CU: what the LDS allows (160 KiB per CU), at most 4 x 8 waves
                 const int per_cu = std::max(1, std::min(32 / TILE_WAVES, (int)(160u * 1024u / ta.tile_lds_bytes)));
                 const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
@@ -702,7 +707,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 ta.tile_units = (const UnitDev*)pl->d_tile_units.p + pl->block_first;
                 ta.n_tile_units = pl->n_block_units;
                 ta.tile_lds_bytes = pl->block_lds;
-                ta.tile_ticket = d_qcount[0] + (MAX_SCALES - 8u * (TILE_CLASSES + 1u));
+                ta.tile_ticket = d_qcount[0] + (q_counts - 8u * (TILE_CLASSES + 1u));
                 const int per_cu = two_streams ? e->concurrent_blocks_per_cu : 2;
                 const int tb = (int)std::min<uint64_t>((uint64_t)pl->n_block_units * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
                 const uint32_t deepest = std::min<uint32_t>((uint32_t)pl->stages.size(), handover);
@@ -763,7 +768,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         // read back the counters block
         HIP_TRY(hipMemcpyAsync(e->h_pinned, e->d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
-        const uint32_t n_det = ((const uint32_t*)e->h_pinned)[MAX_PASSES * MAX_SCALES];
+        const uint32_t n_det = ((const uint32_t*)e->h_pinned)[MAX_PASSES * q_counts];
         float ms_i = 0, ms_c = 0, ms_t = 0;
         HIP_TRY(hipEventElapsedTime(&ms_i, e->ev[0], e->ev[1]));
         HIP_TRY(hipEventElapsedTime(&ms_c, e->ev[2], e->ev[3]));
@@ -795,7 +800,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 tm->launch[i] = linfo[i];
                 tm->launch[i].ms = acc.ms + ms;
                 const unsigned long long* se = (const unsigned long long*)((const uint32_t*)e->h_pinned +
-                                                                           MAX_PASSES * MAX_SCALES + 2) + (1 + i) * VJ_MAX_STAGES;
+                                                                           MAX_PASSES * q_counts + 2) + (1 + i) * VJ_MAX_STAGES;
                 for (size_t s = 0; s < (size_t)VJ_MAX_STAGES; ++s)
                     tm->launch[i].stage_entered[s] = acc.stage_entered[s] + (count ? se[s] : 0ull);
             }
@@ -804,7 +809,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
 #ifdef VJ_STAMPS
         if (getenv("VJ_DEBUG_STAMPS")) {  // diagnostic build (-DVJ_STAMPS=1): phase cycle sums of the tile kernel
             const unsigned long long* se =
-                (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * MAX_SCALES + 2);
+                (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * q_counts + 2);
             fprintf(stderr, "vj stamps:");
             for (int i = 40; i < 60; ++i) {
                 unsigned long long v = 0;
@@ -816,7 +821,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
 #endif
         if (count) {
             const unsigned long long* se =
-                (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * MAX_SCALES + 2);
+                (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * q_counts + 2);
             for (size_t s = 0; s < pl->stages.size(); ++s)
                 for (int l = 1; l <= VJ_MAX_LAUNCHES; ++l) ctr->stage_entered[s] += se[(size_t)l * VJ_MAX_STAGES + s];
         }
@@ -873,7 +878,7 @@ int vj_env_create(int device_index, vj_env** out) {
     HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
-    e->h_pinned_bytes = 32768;
+    e->h_pinned_bytes = 65536;
     HIP_TRY(hipHostMalloc(&e->h_pinned, e->h_pinned_bytes, hipHostMallocDefault));
     if (const char* s = getenv("VJ_BLOCKS_PER_CU")) e->blocks_per_cu = std::max(1, atoi(s));
     if (const char* s = getenv("VJ_PASS_SPLIT")) {  // e.g. "4,9,15"

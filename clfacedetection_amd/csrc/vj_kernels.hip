@@ -547,12 +547,19 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
     return n;
 }
 
+// Which part of a scale's queue segment the windows of `frame` go to: frames are grouped in order, at most
+// ceil(n_frames / Q_PARTS) per part (the host sizes the parts for that), so that a part holds few frames — the
+// working set of whoever drains it.
+__device__ __forceinline__ uint32_t frame_part(const CascadeArgs& a, uint32_t frame) {
+    return a.n_frames >= Q_PARTS ? (uint32_t)((unsigned long long)frame * Q_PARTS / a.n_frames) : frame;
+}
+
 // Global-gather pass body: sweep the stages, then hand the survivors to the next pass's
 // global queue (or to the detection list).
 template <bool TREES, bool LAST, bool COUNT>
 __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t img_r, QEntry* q, uint32_t n,
                                                   uint32_t scale_slot, uint32_t table_first, uint32_t q_base,
-                                                  uint32_t lane, uint32_t begin) {
+                                                  uint32_t lane, uint32_t begin, uint32_t part) {
     kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + table_first;
     const GlobalImg img{img_r};
     n = sweep_stages<TREES, COUNT>(a, img, table, q, n, lane, begin, a.stage_end);
@@ -565,9 +572,11 @@ __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t i
             if (g + i < a.det_cap) a.det[g + i] = DetEntry{q[i].off, scale_slot};
     } else {
         uint32_t g = 0;
-        if (lane == 0) g = atomicAdd(a.q_out_count + scale_slot, n);
+        // the scale's queue segment has Q_PARTS parts of q_part_cap entries: one per group of frames
+        if (lane == 0) g = atomicAdd(a.q_out_count + scale_slot * Q_PARTS + part, n);
         g = __builtin_amdgcn_readfirstlane(g);
-        for (uint32_t i = lane; i < n; i += 64u) a.q_out[(size_t)q_base + g + i] = q[i];
+        const size_t base = (size_t)q_base + (size_t)part * as_k(a.scales)[scale_slot].q_cap;
+        for (uint32_t i = lane; i < n; i += 64u) a.q_out[base + g + i] = q[i];
     }
 }
 
@@ -703,34 +712,47 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
                                                  scales[slot].table_first, lane);
             else
                 run_stages_linear<TREES, LAST, COUNT>(a, img, q, n_q, slot, scales[slot].table_first,
-                                                      scales[slot].q_base, lane, a.stage_begin);
+                                                      scales[slot].q_base, lane, a.stage_begin, frame_part(a, frame));
             __builtin_amdgcn_wave_barrier();
         }
     } else {
+        // Queue pass.  Every scale's segment is cut into Q_PARTS parts by frame group (frame_part); the waves that
+        // share an XCD work through "their" part first — the frames whose sum images their L2 already holds from
+        // the previous pass — and then steal chunks from the other parts.  Chunks are handed out by one ticket
+        // counter per part; ticket t of part x is the t-th chunk of that part's scales taken in order.
         kptr<uint32_t> counts = as_k(a.q_in_count);
-        // chunk size: spread this pass's windows over all waves (a wave works through its chunk
-        // serially, ~1 us per stump, so late passes with few windows want small chunks), in
-        // whole 64-lane groups, at most the LDS queue capacity
+        // chunk size: spread this pass's windows over all waves (a wave works through its chunk serially, ~1 us
+        // per stump, so late passes with few windows want small chunks), in whole 64-lane groups, at most the
+        // LDS queue capacity
         uint32_t total = 0;
-        for (uint32_t slot = 0; slot < a.n_scales; ++slot) total += counts[slot];
+        for (uint32_t i = 0; i < a.n_scales * Q_PARTS; ++i) total += counts[i];
         const uint32_t chunk = min((uint32_t)UNIT_WINDOWS, max(64u, ((total / a.total_waves + 63u) / 64u) * 64u));
-        uint32_t start = 0;  // chunks of all previous scales; chunk c of scale k is virtual unit start + c
-        for (uint32_t slot = 0; slot < a.n_scales; ++slot) {
-            const uint32_t cnt = counts[slot];
-            const uint32_t n_chunks = (cnt + chunk - 1u) / chunk;
-            const uint32_t q_base = scales[slot].q_base;
-            const uint32_t table_first = scales[slot].table_first;
-            // first chunk of this scale owned by this wave: start + c == rank (mod total_waves)
-            uint32_t c = (rank + a.total_waves - start % a.total_waves) % a.total_waves;
-            for (; c < n_chunks; c += a.total_waves) {
-                const uint32_t c0 = c * chunk;
-                const uint32_t n = min(cnt - c0, chunk);
-                for (uint32_t i = lane; i < n; i += 64u) q[i] = a.q_in[(size_t)q_base + c0 + i];
-                __builtin_amdgcn_wave_barrier();
-                run_stages_linear<TREES, LAST, COUNT>(a, img, q, n, slot, table_first, q_base, lane, a.stage_begin);
-                __builtin_amdgcn_wave_barrier();
+        uint32_t part = a.xcd_affinity != 0u ? (blockIdx.x & (Q_PARTS - 1u)) : 0u;
+        for (uint32_t tries = 0; tries < Q_PARTS;) {
+            uint32_t t = 0;
+            if (lane == 0) t = atomicAdd(a.q_ticket + part, 1u);
+            t = __builtin_amdgcn_readfirstlane(t);
+            // ticket -> (scale, chunk): walk the part's scales
+            uint32_t slot = 0, c = t;
+            for (; slot < a.n_scales; ++slot) {
+                const uint32_t n_chunks = (counts[slot * Q_PARTS + part] + chunk - 1u) / chunk;
+                if (c < n_chunks) break;
+                c -= n_chunks;
             }
-            start += n_chunks;
+            if (slot == a.n_scales) {   // this part is used up: steal from the next one
+                part = (part + 1u) & (Q_PARTS - 1u);
+                ++tries;
+                continue;
+            }
+            const uint32_t cnt = counts[slot * Q_PARTS + part];
+            const uint32_t q_base = scales[slot].q_base;
+            const size_t base = (size_t)q_base + (size_t)part * scales[slot].q_cap;
+            const uint32_t c0 = c * chunk;
+            const uint32_t n = min(cnt - c0, chunk);
+            for (uint32_t i = lane; i < n; i += 64u) q[i] = a.q_in[base + c0 + i];
+            __builtin_amdgcn_wave_barrier();
+            run_stages_linear<TREES, LAST, COUNT>(a, img, q, n, slot, scales[slot].table_first, q_base, lane, a.stage_begin, part);
+            __builtin_amdgcn_wave_barrier();
         }
     }
 }
@@ -1428,9 +1450,11 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
             // survivors: tile-local offset -> global byte offset in the batch sum image
             const bool is_det = dest == a.n_pass;
             uint32_t g = 0;
-            if (lane == 0) g = is_det ? atomicAdd(a.det_count, n) : atomicAdd(a.q_pass_count[dest] + slot, n);
+            const uint32_t part = frame_part(a, frame);
+            if (lane == 0)
+                g = is_det ? atomicAdd(a.det_count, n) : atomicAdd(a.q_pass_count[dest] + slot * Q_PARTS + part, n);
             g = __builtin_amdgcn_readfirstlane(g);
-            const uint32_t q_base = scales[slot].q_base;
+            const size_t q_base = (size_t)scales[slot].q_base + (size_t)part * scales[slot].q_cap;
             QEntry* qd = is_det ? nullptr : a.q_pass[dest];
             for (uint32_t i = lane; i < n; i += 64u) {
                 const QEntry e = q[i];
@@ -1444,7 +1468,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                 if (is_det) {
                     if (g + i < a.det_cap) a.det[g + i] = DetEntry{off, slot};
                 } else {
-                    qd[(size_t)q_base + g + i] = QEntry{off, e.var};
+                    qd[q_base + g + i] = QEntry{off, e.var};
                 }
             }
         }
