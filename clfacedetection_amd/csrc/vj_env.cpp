@@ -376,14 +376,14 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
 
 // (Re)lay out the per-scale queue segments for `frames` frames in flight.
 static int layout_queues(Plan* pl, int frames, uint64_t* total_entries) {
-    // a scale's segment: Q_PARTS parts, part x takes the windows of frames with frame * Q_PARTS / frames == x
-    // (frame itself when frames < Q_PARTS), i.e. at most ceil(frames / Q_PARTS) frames
+    // a scale's segment: Q_PARTS parts, part x takes the windows of frames with frame * Q_PARTS / frames == x,
+    // i.e. at most ceil(frames / Q_PARTS) frames (fewer frames than parts: one part per frame, the rest unused)
     const uint64_t frames_per_part = frames >= (int)Q_PARTS ? ((uint64_t)frames + Q_PARTS - 1) / Q_PARTS : 1;
     uint64_t base = 0;
     for (ScaleDev& sd : pl->scales) {
         sd.q_base = (uint32_t)base;
         sd.q_cap = (uint32_t)((uint64_t)sd.nwin * frames_per_part);
-        base += (uint64_t)sd.nwin * frames_per_part * Q_PARTS;
+        base += (uint64_t)sd.nwin * frames_per_part * std::min<uint64_t>(Q_PARTS, (uint64_t)frames);
     }
     *total_entries = base;
     if (base > 0xffffffffull) {
@@ -1165,9 +1165,14 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
     const uint64_t frame_bytes = (uint64_t)pl->frame_elems * 4u;
     uint64_t max_frames = (0xffffffffull - (uint64_t)pl->max_reach_elems * 4u - 16u) / frame_bytes;
     const uint64_t q_budget = 6ull << 30;  // bytes per queue
-    if (pl->windows_per_frame)
-        max_frames = std::min<uint64_t>(max_frames, std::max<uint64_t>(1, q_budget / (pl->windows_per_frame * sizeof(QEntry))));
-    max_frames = std::min<uint64_t>(max_frames, std::max<uint64_t>(1, 0xffffffffull / std::max<uint64_t>(1, pl->windows_per_frame)));
+    // a queue holds Q_PARTS parts of ceil(frames / Q_PARTS) frames' worth of windows each (layout_queues)
+    auto fit_parts = [](uint64_t frames_worth) {
+        return frames_worth >= Q_PARTS ? frames_worth / Q_PARTS * Q_PARTS : std::max<uint64_t>(1, frames_worth);
+    };
+    if (pl->windows_per_frame) {
+        max_frames = std::min<uint64_t>(max_frames, fit_parts(q_budget / (pl->windows_per_frame * sizeof(QEntry))));
+        max_frames = std::min<uint64_t>(max_frames, fit_parts(0xffffffffull / pl->windows_per_frame));
+    }
     if (e->max_subbatch > 0) max_frames = std::min<uint64_t>(max_frames, (uint64_t)e->max_subbatch);
     if (max_frames == 0) {
         set_error("a single frame exceeds the 32-bit offset range");

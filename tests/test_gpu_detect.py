@@ -76,16 +76,19 @@ def test_detect_matches_live_oracle_large(env, oracle, cascades, casc, kind, h, 
 
 
 def test_batch_equals_single_frames(env, oracle, cascades):
-    """Frames of a batch are independent: batch result == per-frame results, frame index kept."""
+    """Frames of a batch are independent: batch result == per-frame results, frame index kept — for batch sizes
+    below, at and above the number of queue parts (frames are grouped into 8 parts by index)."""
     c, a = cascades("frontalface_alt")
-    frames = synth.batch(7, 270, 360, seed0=300)
-    rb = env.detect(c, frames, default_params(flags=VJ_FLAG_COUNTERS))
-    total = [0] * c.info.n_stages
-    for f in range(len(frames)):
-        ro, st = oracle.detect(a, frames[f])
-        assert as_list(rb.rects[rb.rects["frame"] == f]) == as_list(ro)
-        total = [x + y for x, y in zip(total, st["stage_entered"])]
-    assert rb.stage_entered == total
+    frames = synth.batch(19, 270, 360, seed0=300)
+    per_frame = [oracle.detect(a, f) for f in frames]
+    for n in (1, 7, 8, 9, 19):
+        rb = env.detect(c, frames[:n], default_params(flags=VJ_FLAG_COUNTERS))
+        total = [0] * c.info.n_stages
+        for f in range(n):
+            ro, st = per_frame[f]
+            assert as_list(rb.rects[rb.rects["frame"] == f]) == as_list(ro), (n, f)
+            total = [x + y for x, y in zip(total, st["stage_entered"])]
+        assert rb.stage_entered == total, n
     assert np.all(np.diff(rb.rects["frame"]) >= 0)
 
 
