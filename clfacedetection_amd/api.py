@@ -29,7 +29,6 @@ from .build import LIB_PATH, build_lib
 VJ_MAX_STAGES = 64
 VJ_FLAG_COUNTERS = 1 << 0
 VJ_FLAG_SIGNED_MEAN = 1 << 1
-VJ_FLAG_TABLE_IN_LDS = 1 << 2
 
 # clod_flags of the reference (clod.h:17-19).  They select among the reference's CPU
 # evaluators; the HIP path has one evaluator, so they are accepted and ignored.

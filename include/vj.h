@@ -100,8 +100,6 @@ enum {
                                        pixel sum read through int* (differs from
                                        the default unsigned read only when the
                                        sum >= 2^31)            */
-    VJ_FLAG_TABLE_IN_LDS = 1u << 2  /* stage tables staged in LDS instead of the
-                                       scalar cache (same results)               */
 };
 
 typedef struct vj_params {
