@@ -97,6 +97,7 @@ constexpr int TILE_CLASSES = 3;       // LDS size classes, one launch each
 constexpr int TILE_LDS_HEADER = (TILE_WAVES * TILE_WAVE_CAP * 2 + 32) * 4;  // queues + per-wave counts, bytes
 constexpr int TILE_SP_MAX_WINDOWS = 256;  // windows a tile may carry into the finish: entries + verdict masks + partial sums fit the 16 KiB queue area
 constexpr int TILE_WS_MAX_WINDOWS = 512;  // wave-split finish: 8 chunks of packed entries (4 KiB) + 8 x 320 dwords of sums and verdict words
+constexpr int TILE_SEG_MAX_WINDOWS = 256;  // stage-tree chains inside a tile: population + reject list (256 entries each) around the scratch
 constexpr int TILE_SP_MAX_BLOCKS = 4;     // blocks of 64 stumps per stage at most (stages of <= 256 nodes)
 constexpr int TILE_SP_BLOCK = 64;         // stumps evaluated per round and window (= lanes of a wave)
 constexpr int TILE_SP_FIELDS = 14;        // dwords of a node record kept in the LDS copy of a stage's table
@@ -126,6 +127,8 @@ struct CascadeArgs {
     uint32_t* q_ticket;         // Q_PARTS chunk-ticket counters of this queue pass (zeroed before the launch)
     QEntry*   q_out;            // survivor queue written by this pass (not the last)
     uint32_t* q_out_count;
+    QEntry*   q_fail;           // stage trees: queue of the chain that takes this pass's rejects (else null)
+    uint32_t* q_fail_count;
     // Tile launches: one survivor queue per pass boundary.  A wave sweeps the cascade one
     // pass segment at a time and leaves at boundary p — appending to queue p — as soon as
     // fewer than tile_min_lanes windows survive (or the boundary is >= tile_end).
@@ -142,6 +145,9 @@ struct CascadeArgs {
     uint32_t  tile_sp_begin;                // >= number of stages: disabled
     uint32_t  tile_sp_pad;                  // dwords of LDS reserved for the finish: two record blocks + leaf values (0 = off)
     uint32_t  tile_sp_max;                  // enter the finish when at most this many windows are left
+    uint32_t  n_seg;                        // stage tree: chains after the linear prefix that a tile may run itself (0: none)
+    uint32_t  seg_end[4];                   // ... end position (sweep order) of chain k; it starts where chain k-1 (or the prefix) ends
+    uint32_t  seg_chain;                    // ... bit k: the rejects of chain k are the population of chain k+1
     uint32_t  tree2;                        // every tree has exactly two nodes, the second one the child of the first
     uint32_t  tile_finish;                  // 0: stump-parallel finish, 1: wave-split finish (tile_wave_split)
     uint32_t  tile_ws_min;                  // ... and hand over to the stump-parallel finish below this many

@@ -130,6 +130,14 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         }
         order.assign(post.rbegin(), post.rend());  // reverse post-order; unreachable stages are dropped
     }
+    if (pl->general && e->general_prefix) {
+        // the linear head of a stage tree (frontalface_alt_tree: stages 0..4 before the two chains split)
+        uint32_t P = 0;
+        while (P + 1 < order.size() && order[P] == P && pl->prog.on_fail[P] == STAGE_REJECT &&
+               pl->prog.on_pass[P] == (int)(P + 1) && order[P + 1] == P + 1)
+            ++P;
+        if (P >= 2) pl->general_prefix = P;
+    }
     pl->scales_all = plan_scales(c, W, H, p);
     pl->frame_elems = frame_elems_for(W, H);
     const uint32_t stride = (uint32_t)W + 1u;
@@ -196,7 +204,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                     reach_y = std::max(reach_y, lt / stride + (r.dh[q] / 4u) / stride);
                 }
         }
-        if (!pl->general && si.ny < 65536 && si.nx < 65536) {
+        if ((!pl->general || pl->general_prefix) && si.ny < 65536 && si.nx < 65536) {
             // candidate tile shapes; per class the shape with the most windows that fits wins
             static const uint32_t kTw[] = {64, 48, 32, 24, 16, 12, 8}, kTh[] = {32, 24, 16, 12, 8, 6, 4};
             uint32_t best_cls = TILE_CLASSES, best_n = 0, b_tw = 0, b_th = 0, b_pitch = 0, b_rows = 0;
@@ -326,7 +334,74 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         }
     }
     pl->pass_bounds = default_pass_bounds(c, pl->prog, e->split_override);
-    if (pl->general) pl->pass_bounds = {0u, pl->n_order};  // one pass over StageDev::order (run_stages_general)
+    if (pl->general) {   // positions in StageDev::order: [linear prefix | the rest]
+        if (pl->general_prefix) pl->pass_bounds = {0u, pl->general_prefix, pl->n_order};
+        else pl->pass_bounds = {0u, pl->n_order};
+        // Can the rest be cut into linear segments?  A segment is a run of positions whose pass edges follow the
+        // order, whose rejects all go to the first position of a LATER segment (or are final), and whose end accepts.
+        if (pl->general_prefix) {
+            struct Seg { uint32_t b, e; int fail_pos; };
+            std::vector<Seg> segs;
+            std::vector<int> pos_of(c.stages.size(), -1);
+            for (uint32_t i = 0; i < pl->n_order; ++i) pos_of[order[i]] = (int)i;
+            bool ok = true;
+            uint32_t b = pl->general_prefix;
+            while (b < pl->n_order && ok) {
+                const int f = pl->prog.on_fail[order[b]];
+                uint32_t e2 = b;
+                while (true) {
+                    const uint32_t sid = order[e2];
+                    if (pl->prog.on_fail[sid] != f) { ok = false; break; }
+                    const int np = pl->prog.on_pass[sid];
+                    ++e2;
+                    if (np == STAGE_ACCEPT) break;
+                    if (e2 >= pl->n_order || np != (int)order[e2]) { ok = false; break; }
+                }
+                if (!ok) break;
+                segs.push_back(Seg{b, e2, f == STAGE_REJECT ? -1 : pos_of[f]});
+                b = e2;
+            }
+            for (const Seg& sg : segs)   // a reject target must be the start of a later segment
+                if (sg.fail_pos >= 0) {
+                    bool found = false;
+                    for (const Seg& t : segs) found |= t.b == (uint32_t)sg.fail_pos && t.b >= sg.e;
+                    ok &= found;
+                }
+            // passes: the prefix, then every segment in two parts (its first stages see most of its windows)
+            std::vector<uint32_t> bounds{0u, pl->general_prefix};
+            std::vector<uint8_t> last{0}, failq{0};   // index = pass; entry 0 = the prefix pass
+            std::vector<int> seg_first_pass;
+            for (const Seg& sg : segs) {
+                seg_first_pass.push_back((int)bounds.size() - 1);
+                const uint32_t cut = sg.e - sg.b > 4 ? sg.b + 3 : sg.e;
+                if (cut < sg.e) { bounds.push_back(cut); last.push_back(0); failq.push_back(0); }
+                bounds.push_back(sg.e); last.push_back(1); failq.push_back(0);
+            }
+            if (ok && !segs.empty() && bounds.size() - 1 <= (size_t)VJ_MAX_PASSES) {
+                for (size_t k = 0; k < segs.size(); ++k) {
+                    if (segs[k].fail_pos < 0) continue;
+                    int target_pass = -1;
+                    for (size_t t = 0; t < segs.size(); ++t)
+                        if (segs[t].b == (uint32_t)segs[k].fail_pos) target_pass = seg_first_pass[t];
+                    const int p_end = k + 1 < segs.size() ? seg_first_pass[k + 1] : (int)bounds.size() - 1;
+                    for (int ps = seg_first_pass[k]; ps < p_end; ++ps) failq[(size_t)ps] = (uint8_t)target_pass;
+                }
+                pl->pass_bounds = bounds;
+                pl->seg_last = last;
+                pl->seg_fail = failq;
+                bool chain_ok = segs.size() <= 4;
+                for (size_t k = 0; k < segs.size() && chain_ok; ++k)
+                    if (segs[k].fail_pos >= 0 && (k + 1 >= segs.size() || segs[k + 1].b != (uint32_t)segs[k].fail_pos)) chain_ok = false;
+                if (chain_ok) {
+                    pl->tile_n_seg = (uint32_t)segs.size();
+                    for (size_t k = 0; k < segs.size(); ++k) {
+                        pl->tile_seg_end[k] = segs[k].e;
+                        if (segs[k].fail_pos >= 0) pl->tile_seg_chain |= 1u << k;
+                    }
+                }
+            }
+        }
+    }
     // tile launches run deeper than the global-gather first pass (LDS gathers are ~10x cheaper)
     pl->tile_end = std::min<uint32_t>((uint32_t)c.stages.size(), std::max<uint32_t>((uint32_t)e->tile_end, pl->pass_bounds[1]));
     if (pl->pass_bounds.size() == 2) pl->tile_end = pl->pass_bounds[1];
@@ -600,11 +675,14 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             ca.q_pass[ps] = (QEntry*)e->d_q[ps].p;
             ca.q_pass_count[ps] = d_qcount[ps];
         }
-        ca.tile_end = (uint32_t)e->tile_end;
+        ca.tile_end = pl->general ? pl->general_prefix : (uint32_t)e->tile_end;   // stage trees: tiles run the linear prefix only
         ca.tile_min_lanes = (uint32_t)e->tile_min_lanes;
         ca.tile_repack_mask = e->tile_repack_mask;
         ca.tile_sp_begin = (pl->sp_pad || pl->tree2) ? (uint32_t)e->tile_sp_begin : 0xffffffffu;
         ca.tree2 = pl->tree2 ? 1u : 0u;
+        ca.n_seg = e->tile_segments ? pl->tile_n_seg : 0u;
+        for (int k = 0; k < 4; ++k) ca.seg_end[k] = pl->tile_seg_end[k];
+        ca.seg_chain = pl->tile_seg_chain;
         ca.tile_sp_pad = pl->sp_pad;
         ca.sp_blocks = (const SpBlock*)pl->d_sp_blocks.p;
         ca.n_sp_blocks = pl->n_sp_blocks;
@@ -642,11 +720,13 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             if (linfo.size() <= VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(e->launch_ev[2 * linfo.size() - 1], st));
             return VJ_OK;
         };
+        auto pass_is_last = [&](size_t ps) { return pl->seg_last.empty() ? ps + 1 == n_pass : pl->seg_last[ps] != 0; };
+        const bool general_kernel = pl->general && pl->seg_last.empty();   // run_stages_general finishes the tree
         auto queue_args = [&](size_t ps) {
             CascadeArgs qa = ca;
             qa.stage_begin = pl->pass_bounds[ps];
             qa.stage_end = pl->pass_bounds[ps + 1];
-            const bool last = ps + 1 == n_pass;
+            const bool last = pass_is_last(ps);
             // pass ps reads queue ps (filled by pass ps-1 and by tiles that left at this boundary)
             // and appends its survivors to queue ps+1
             qa.q_in = (const QEntry*)e->d_q[ps].p;
@@ -654,6 +734,10 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             qa.q_ticket = d_qcount[0] + ps * Q_PARTS;   // queue 0 does not exist: its counters serve as tickets
             qa.q_out = last ? nullptr : (QEntry*)e->d_q[ps + 1].p;
             qa.q_out_count = last ? nullptr : d_qcount[ps + 1];
+            if (!pl->seg_fail.empty() && pl->seg_fail[ps] != 0) {   // stage tree: this segment's rejects continue
+                qa.q_fail = (QEntry*)e->d_q[pl->seg_fail[ps]].p;
+                qa.q_fail_count = d_qcount[pl->seg_fail[ps]];
+            }
             return qa;
         };
         if (ca.n_units + ca.n_tile_units > 0) {
@@ -664,7 +748,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             //                   (texture-address-bound) — every pass that begins before the stage at
             //                   which tiles hand over (tiles leave at one boundary when tile_min_lanes = 0)
             // then B joins A and the remaining queue passes run on A.
-            const uint32_t handover = pl->general ? 0u : std::max<uint32_t>(ca.tile_end, pl->pass_bounds[1]);
+            const uint32_t handover = pl->general ? pl->general_prefix : std::max<uint32_t>(ca.tile_end, pl->pass_bounds[1]);
             size_t first_joint_pass = 1;
             if (e->tile_min_lanes == 0)
                 while (first_joint_pass < n_pass && pl->pass_bounds[first_joint_pass] < handover) ++first_joint_pass;
@@ -720,14 +804,14 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 ga.total_waves = (uint32_t)b_blocks * WAVES_PER_BLOCK;
                 if ((rc = begin_launch(VJ_LAUNCH_GRID, 0, ga.stage_begin, ga.stage_end, 0, sB))) return rc;
                 ga.stage_entered = launch_counters();
-                hrc = launch_cascade_pass(ga, true, pl->trees, n_pass == 1, count, pl->general, b_blocks, sB);
+                hrc = launch_cascade_pass(ga, true, pl->trees, n_pass == 1, count, general_kernel && n_pass == 1, b_blocks, sB);
                 if ((rc = end_launch(sB))) return rc;
                 for (size_t ps = 1; ps < first_joint_pass && !hrc; ++ps) {
                     CascadeArgs qa = queue_args(ps);
                     qa.total_waves = (uint32_t)b_blocks * WAVES_PER_BLOCK;
                     if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, sB))) return rc;
                     qa.stage_entered = launch_counters();
-                    hrc = launch_cascade_pass(qa, false, pl->trees, ps + 1 == n_pass, count, false, b_blocks, sB);
+                    hrc = launch_cascade_pass(qa, false, pl->trees, pass_is_last(ps), count, false, b_blocks, sB);
                     if ((rc = end_launch(sB))) return rc;
                 }
             } else {
@@ -754,7 +838,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 CascadeArgs qa = queue_args(ps);
                 if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, e->stream))) return rc;
                 qa.stage_entered = launch_counters();
-                hrc = launch_cascade_pass(qa, false, pl->trees, ps + 1 == n_pass, count, false, n_blocks, e->stream);
+                hrc = launch_cascade_pass(qa, false, pl->trees, pass_is_last(ps), count, general_kernel, n_blocks, e->stream);
                 if ((rc = end_launch(e->stream))) return rc;
             }
             if (hrc) {
@@ -1043,6 +1127,16 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "xcd_affinity") == 0) {
         e->xcd_affinity = atoi(value) != 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_segments") == 0) {
+        e->tile_segments = atoi(value) != 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "general_prefix") == 0) {
+        e->general_prefix = atoi(value) != 0;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
         return VJ_OK;
     }
     if (strcmp(key, "grid_block_w") == 0) {

@@ -71,6 +71,14 @@ struct Plan {
     uint32_t max_reach_elems = 0;  // furthest element a window origin + feature corner touches
     bool trees = false;    // some tree has more than one node
     bool general = false;  // stage tree (not a linear chain of stages)
+    uint32_t general_prefix = 0;  // stage tree: positions [0, prefix) of the sweep order form a linear chain (pass -> next,
+                                  // fail -> reject) that runs on the linear kernels (tiles included)
+    // Stage tree cut into linear segments (chains of the sweep order whose rejects all go to one place): pass ps reads
+    // queue ps; seg_last[ps]: its survivors are detections; seg_fail[ps]: queue that takes its rejects (0 = none).
+    // Empty when the tree does not have that shape: then one general pass (run_stages_general) finishes it.
+    std::vector<uint8_t> seg_last, seg_fail;
+    // the same chains for the tile kernel, which runs them itself when chain k's rejects feed chain k+1
+    uint32_t tile_n_seg = 0, tile_seg_end[4] = {}, tile_seg_chain = 0;
     uint32_t n_order = 0;  // stages reachable from stage 0, in StageDev::order
     StageProgram prog;
     // device copies
@@ -95,6 +103,8 @@ struct vj_env {
     int concurrent_blocks_per_cu = 1;   // workgroups per CU of the global-gather chain while it overlaps
     float tile_split = 0.5f;            // scales' worth of tile work handed to the global-gather chain (largest tile scales first)
     int xcd_affinity = 1;               // global-gather first pass: one contiguous part of the work per XCD (L2 locality)
+    int tile_segments = 1;              // stage trees: tiles run the chains after the prefix themselves
+    int general_prefix = 1;             // stage trees: run their linear prefix on the linear kernels (0: one general pass)
     int grid_block_w = 32;              // width of the 2-D window blocks of the global-gather first pass (0: row runs)
     int global_blocks = 0;              // 1: large scales run as unstaged 2-D blocks in the tile kernel (stump cascades): 2.2x
                                         // faster than grid + queue passes on its own, but it overlaps the tile chain badly

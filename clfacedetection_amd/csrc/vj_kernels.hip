@@ -453,11 +453,21 @@ __device__ __forceinline__ float stage_sum_of(const Img& img, kptr<NodeRecDev> t
 // over the wave's LDS queue q[0..n) (all entries belong to one scale and sit at the same
 // stage — linear cascades), compacting survivors in place after every stage.  Returns
 // the number of survivors left at q[0..).
+// Where the windows a stage REJECTS go, for the segments of a stage tree whose failures continue in another
+// chain (frontalface_alt_tree: failing anywhere in the first chain after stage 4 starts the second one).
+struct FailSink {
+    QEntry* base = nullptr;      // the (scale, part) sub-queue of the chain that takes them
+    uint32_t* count = nullptr;
+};
+
 template <bool TREES, bool COUNT, bool MULTI = false, typename Img>
 __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img& img, kptr<NodeRecDev> table,
-                                                 QEntry* q, uint32_t n, uint32_t lane, uint32_t begin, uint32_t end) {
+                                                 QEntry* q, uint32_t n, uint32_t lane, uint32_t begin, uint32_t end,
+                                                 FailSink fail = FailSink()) {
     kptr<StageDev> stages = as_k(a.stages);
-    for (uint32_t s = begin; s < end && n != 0u; ++s) {
+    for (uint32_t pos = begin; pos < end && n != 0u; ++pos) {
+        // [begin, end) are positions in the sweep order (StageDev::order); a linear cascade's order is 0, 1, 2, ...
+        const uint32_t s = stages[pos].order;
         const uint32_t first_node = stages[s].first_node;
         const uint32_t n_nodes = stages[s].n_nodes;
         const float threshold = stages[s].threshold;
@@ -536,6 +546,15 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
                     pass = stage_sum_of<TREES>(img, tab, n_nodes, e.off, e.var) >= threshold;
                 }
             }
+            if (!MULTI && fail.base != nullptr) {   // uniform: this segment's rejects continue elsewhere
+                const unsigned long long fm = __ballot(act && !pass);
+                if (fm != 0ull) {
+                    uint32_t g = 0;
+                    if (lane == 0) g = atomicAdd(fail.count, (uint32_t)__popcll(fm));
+                    g = __builtin_amdgcn_readfirstlane(g);
+                    if (act && !pass) fail.base[g + mbcnt(fm)] = e;
+                }
+            }
             const unsigned long long mask = __ballot(pass);
             __builtin_amdgcn_wave_barrier();   // every lane has read its entry before any lane overwrites
             if (pass) q[m + mbcnt(mask)] = e;  // m + rank <= i: never ahead of the read cursor
@@ -562,7 +581,12 @@ __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t i
                                                   uint32_t lane, uint32_t begin, uint32_t part) {
     kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + table_first;
     const GlobalImg img{img_r};
-    n = sweep_stages<TREES, COUNT>(a, img, table, q, n, lane, begin, a.stage_end);
+    FailSink fail;
+    if (a.q_fail != nullptr) {
+        fail.base = a.q_fail + ((size_t)q_base + (size_t)part * as_k(a.scales)[scale_slot].q_cap);
+        fail.count = a.q_fail_count + scale_slot * Q_PARTS + part;
+    }
+    n = sweep_stages<TREES, COUNT>(a, img, table, q, n, lane, begin, a.stage_end, fail);
     if (n == 0u) return;
     if (LAST) {
         uint32_t g = 0;
@@ -751,7 +775,10 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
             const uint32_t n = min(cnt - c0, chunk);
             for (uint32_t i = lane; i < n; i += 64u) q[i] = a.q_in[base + c0 + i];
             __builtin_amdgcn_wave_barrier();
-            run_stages_linear<TREES, LAST, COUNT>(a, img, q, n, slot, scales[slot].table_first, q_base, lane, a.stage_begin, part);
+            if (GENERAL)   // the rest of a stage tree, for the survivors of its linear prefix
+                run_stages_general<TREES, COUNT>(a, img, q, lds_tgt + wib * UNIT_WINDOWS, n, slot, scales[slot].table_first, lane);
+            else
+                run_stages_linear<TREES, LAST, COUNT>(a, img, q, n, slot, scales[slot].table_first, q_base, lane, a.stage_begin, part);
             __builtin_amdgcn_wave_barrier();
         }
     }
@@ -1053,15 +1080,17 @@ template <bool COUNT, bool TREE2, typename Img>
 __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const Img& img, kptr<NodeRecDev> table,
                                                     QEntry* lds_q, uint32_t* lds_cnt, uint32_t T, uint32_t& st_io,
                                                     uint32_t n_stages, uint32_t lane, uint32_t wib,
-                                                    unsigned long long& t_last) {
+                                                    unsigned long long& t_last, QEntry* fail_list = nullptr,
+                                                    uint32_t* fail_n = nullptr) {
     unsigned long long sp_acc[5] = {0, 0, 0, 0, 0};
     constexpr bool STAMPS = true;
     kptr<StageDev> stages = as_k(a.stages);
     // scratch behind the packed entries: per producing wave 64 range sums + 4 x 64 verdict words
     uint32_t* lds_x = reinterpret_cast<uint32_t*>(lds_q + TILE_WS_MAX_WINDOWS);
-    uint32_t s = st_io;
+    uint32_t pos = st_io;   // position in the sweep order (StageDev::order); a linear cascade's order is 0, 1, 2, ...
     // below tile_ws_min windows a chunk's lanes are mostly empty: the caller continues stump-parallel
-    for (; s < n_stages && T != 0u && T >= a.tile_ws_min; ++s) {
+    for (; pos < n_stages && T != 0u && T >= a.tile_ws_min; ++pos) {
+        const uint32_t s = stages[pos].order;
         if (COUNT && threadIdx.x == 0) atomicAdd(a.stage_entered + s, (unsigned long long)T);
         // items of a stage: stumps, or two-node trees (TREE2: records 2t and 2t+1, a 2-bit leaf code per tree)
         constexpr uint32_t PER_WORD = TREE2 ? 16u : 32u;
@@ -1178,17 +1207,29 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
             }
         }
         SPSTAMP(2);
-        // survivors: compact lds_q across the deciding waves
+        // survivors: compact lds_q across the deciding waves; a stage-tree segment also keeps its rejects, which
+        // continue in another chain (fail_list)
         const unsigned long long mask = __ballot(pass);
-        if (lane == 0) lds_cnt[1u + wib] = (uint32_t)__popcll(mask);
+        const bool rejected = fail_list != nullptr && wib < c && valid && !pass;
+        const unsigned long long fmask = __ballot(rejected);
+        if (lane == 0) {
+            lds_cnt[1u + wib] = (uint32_t)__popcll(mask);
+            lds_cnt[20u + wib] = (uint32_t)__popcll(fmask);
+        }
         lds_barrier();   // every entry is in registers, every wave's count is published
         SPSTAMP(3);
-        uint32_t before = 0, total = 0;
+        uint32_t before = 0, total = 0, fbefore = 0, ftotal = 0;
 #pragma unroll
         for (uint32_t w = 0; w < TILE_WAVES; ++w) {
-            const uint32_t cw = lds_cnt[1u + w];
+            const uint32_t cw = lds_cnt[1u + w], fw = lds_cnt[20u + w];
             before += w < wib ? cw : 0u;
             total += cw;
+            fbefore += w < wib ? fw : 0u;
+            ftotal += fw;
+        }
+        if (fail_list != nullptr) {
+            if (rejected) fail_list[*fail_n + fbefore + mbcnt(fmask)] = e;
+            *fail_n += __builtin_amdgcn_readfirstlane(ftotal);
         }
         if (pass) lds_q[before + mbcnt(mask)] = e;
         T = __builtin_amdgcn_readfirstlane(total);
@@ -1196,7 +1237,7 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
         SPSTAMP(4);
     }
     SPFLUSH();
-    st_io = s;
+    st_io = pos;
     return T;
 }
 
@@ -1374,6 +1415,33 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         // queue — when the boundary lies at or beyond tile_end or fewer than tile_min_lanes
         // windows are left in the tile (the queue passes re-pack windows of the whole batch).
         STAMP(2);
+        // hand a wave's survivors on: detections (dest == n_pass) or the global queue of pass boundary `dest`;
+        // tile-local offsets become byte offsets in the batch sum image
+        auto flush_wave = [&](const QEntry* qq, uint32_t nn, uint32_t dest_) {
+            const bool is_det = dest_ == a.n_pass;
+            const uint32_t part = frame_part(a, frame);
+            uint32_t g = 0;
+            if (lane == 0)
+                g = is_det ? atomicAdd(a.det_count, nn) : atomicAdd(a.q_pass_count[dest_] + slot * Q_PARTS + part, nn);
+            g = __builtin_amdgcn_readfirstlane(g);
+            const size_t q_base = (size_t)scales[slot].q_base + (size_t)part * scales[slot].q_cap;
+            QEntry* qd = is_det ? nullptr : a.q_pass[dest_];
+            for (uint32_t i = lane; i < nn; i += 64u) {
+                const QEntry e = qq[i];
+                uint32_t off = e.off;
+                if (STAGED) {
+                    const uint32_t lo = e.off >> 2;
+                    const uint32_t ly = lo / pitch, lc = lo - ly * pitch;
+                    const uint32_t lx = half ? lc * 2u : lc;   // window origins sit in the even plane
+                    off = frame_bytes + ((y0 + ly) * a.stride + (x0 + lx)) * 4u;
+                }
+                if (is_det) {
+                    if (g + i < a.det_cap) a.det[g + i] = DetEntry{off, slot};
+                } else {
+                    qd[q_base + g + i] = QEntry{off, e.var};
+                }
+            }
+        };
         uint32_t dest = a.n_pass;   // n_pass = ran the whole cascade: survivors are detections
         uint32_t next_p = 1;        // next pass boundary index
         const uint32_t n_stages_total = a.pass_begin[a.n_pass];
@@ -1407,6 +1475,31 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
                 q = lds_q + first;
                 n = min(share, total - first);
                 STAMP(3 + min(st, 8u));   // time of stage st-1 (incl. waiting for the slowest wave) + this re-pack
+                if (!TREES && a.n_seg != 0u && st == a.tile_end && total != 0u && total <= (uint32_t)TILE_SEG_MAX_WINDOWS) {
+                    // Stage tree (frontalface_alt_tree): the linear prefix ends here; the chains that follow run on the
+                    // packed survivors with the wave-split machinery — a chain's rejects are collected in LDS and
+                    // become the population of the next chain — so the whole tree finishes inside the tile.
+                    QEntry* flist = lds_q + (TILE_WS_MAX_WINDOWS + TILE_WAVES * 160);   // behind the wave-split scratch
+                    uint32_t T = total, posn = st;
+                    for (uint32_t k = 0; k < a.n_seg; ++k) {
+                        const bool chained = ((a.seg_chain >> k) & 1u) != 0u;
+                        uint32_t F_n = 0;
+                        const uint32_t left = tile_wave_split<COUNT, false>(a, img, table, lds_q, lds_cnt, T, posn, a.seg_end[k],
+                                                                            lane, wib, t_last, chained ? flist : nullptr, &F_n);
+                        if (wib == 0u && left != 0u) flush_wave(lds_q, left, a.n_pass);   // the chain's end accepts
+                        if (!chained || F_n == 0u) break;
+                        __syncthreads();
+                        for (uint32_t i = threadIdx.x; i < F_n; i += TILE_WAVES * 64u) lds_q[i] = flist[i];
+                        __syncthreads();
+                        T = F_n;
+                        posn = a.seg_end[k];
+                    }
+                    q = lds_q;
+                    n = 0u;
+                    dest = a.n_pass;
+                    STAMP(12);
+                    break;
+                }
                 if ((!TREES || a.tree2) && a.tile_finish == 1u && st >= a.tile_sp_begin && total != 0u && total <= a.tile_ws_max) {
                     // few windows left: finish the whole cascade with the stage's stumps (or two-node trees) split
                     // over the waves
@@ -1446,32 +1539,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
             }
             if (n != 0u) n = sweep_stages<TREES, COUNT, true>(a, img, table, q, n, lane, st, st + 1u);
         }
-        if (n != 0u) {
-            // survivors: tile-local offset -> global byte offset in the batch sum image
-            const bool is_det = dest == a.n_pass;
-            uint32_t g = 0;
-            const uint32_t part = frame_part(a, frame);
-            if (lane == 0)
-                g = is_det ? atomicAdd(a.det_count, n) : atomicAdd(a.q_pass_count[dest] + slot * Q_PARTS + part, n);
-            g = __builtin_amdgcn_readfirstlane(g);
-            const size_t q_base = (size_t)scales[slot].q_base + (size_t)part * scales[slot].q_cap;
-            QEntry* qd = is_det ? nullptr : a.q_pass[dest];
-            for (uint32_t i = lane; i < n; i += 64u) {
-                const QEntry e = q[i];
-                uint32_t off = e.off;
-                if (STAGED) {
-                    const uint32_t lo = e.off >> 2;
-                    const uint32_t ly = lo / pitch, lc = lo - ly * pitch;
-                    const uint32_t lx = half ? lc * 2u : lc;   // window origins sit in the even plane
-                    off = frame_bytes + ((y0 + ly) * a.stride + (x0 + lx)) * 4u;
-                }
-                if (is_det) {
-                    if (g + i < a.det_cap) a.det[g + i] = DetEntry{off, slot};
-                } else {
-                    qd[q_base + g + i] = QEntry{off, e.var};
-                }
-            }
-        }
+        if (n != 0u) flush_wave(q, n, dest);
         STAMP(13);
         __syncthreads();   // the tile is finished: lds_cnt may carry the next ticket
         if (threadIdx.x == 0) lds_cnt[TILE_WAVES + 8] = next_u;
@@ -1518,20 +1586,25 @@ static void launch_variant(const CascadeArgs& a, bool last, bool count, int n_bl
     }
 }
 
-template <bool TREES>
+template <bool FROM_GRID, bool TREES>
 static void launch_general(const CascadeArgs& a, bool count, int n_blocks, hipStream_t stream) {
     dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
-    if (count) hipLaunchKernelGGL((cascade_pass<true, TREES, true, true, true>), g, b, 0, stream, a);
-    else       hipLaunchKernelGGL((cascade_pass<true, TREES, true, false, true>), g, b, 0, stream, a);
+    if (count) hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, true, true>), g, b, 0, stream, a);
+    else       hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, false, true>), g, b, 0, stream, a);
 }
 
 int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool last, bool count, bool general,
                         int n_blocks, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    if (general) {  // stage-tree cascade: the whole cascade in one first-and-last pass
-        if (!from_grid || !last) return (int)hipErrorInvalidValue;
-        if (trees) launch_general<true>(a, count, n_blocks, stream);
-        else       launch_general<false>(a, count, n_blocks, stream);
+    if (general) {  // stage-tree cascade: everything (from the grid) or everything after the linear prefix (from its queue)
+        if (!last) return (int)hipErrorInvalidValue;
+        if (from_grid) {
+            if (trees) launch_general<true, true>(a, count, n_blocks, stream);
+            else       launch_general<true, false>(a, count, n_blocks, stream);
+        } else {
+            if (trees) launch_general<false, true>(a, count, n_blocks, stream);
+            else       launch_general<false, false>(a, count, n_blocks, stream);
+        }
     } else if (from_grid) {
         if (trees) launch_variant<true, true>(a, last, count, n_blocks, stream);
         else       launch_variant<true, false>(a, last, count, n_blocks, stream);

@@ -325,6 +325,20 @@ def test_config4_4096_alt_tree(env, oracle, cascades):
     ro, st = oracle.detect(a, img, min_size=(900, 900))
     assert as_list(big.rects) == as_list(ro) and big.stage_entered == st["stage_entered"]
     assert as_list(r1.rects[r1.rects["w"] >= 900]) == as_list(ro)
+    # the linear prefix of the stage tree (stages 0..4) on the linear kernels + general pass from its queue == the
+    # one-pass general kernel
+    try:
+        env.configure("general_prefix", 0)
+        r0 = env.detect(c, img, p)
+        assert [l["kind"] for l in r0.launches] == ["grid"] and len(r1.launches) > 3     # prefix + the two chains' passes
+        assert np.array_equal(r0.rects, r1.rects) and r0.stage_entered == r1.stage_entered
+        env.configure("general_prefix", 1)
+        env.configure("tile_segments", 0)        # tiles hand over after the prefix instead of running the chains
+        r2 = env.detect(c, img, p)
+        assert np.array_equal(r2.rects, r1.rects) and r2.stage_entered == r1.stage_entered
+    finally:
+        env.configure("general_prefix", 1)
+        env.configure("tile_segments", 1)
 
 
 def test_config5_two_cascades_on_rois(env, oracle, cascades):
