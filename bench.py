@@ -177,6 +177,20 @@ def main() -> int:
             if l["kind"] != "queue":
                 alg += 48 * l["stage_entered"][0]
             alg += 16 * sum(n * rects_per_stage[st] for st, n in enumerate(l["stage_entered"]))
+        # the same figure for every kernel group (the chains overlap, so each kernel's own time is the time it was
+        # resident, not a share of the step)
+        per_kernel = {}
+        for kind, grp in groups.items():
+            b = 0
+            for l in counted.launches:
+                if l["kind"] != kind:
+                    continue
+                if kind != "queue":
+                    b += 48 * l["stage_entered"][0]
+                b += 16 * sum(n * rects_per_stage[st] for st, n in enumerate(l["stage_entered"]))
+            per_kernel[kind] = {"kernel": kname[kind], "launches_per_step": grp["n"], "ms_per_step": round(grp["ms"], 3),
+                                "algorithmic_GB_per_step": round(b / 1e9, 2),
+                                "achieved_GBps": round(b / (grp["ms"] * 1e-3) / 1e9, 1) if grp["ms"] > 0 else None}
         achieved = alg / (dom["ms"] * 1e-3) / 1e9
         traffic = None
         pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")   # from rocprofv3 --pmc passes (tools/pmc_traffic.py)
@@ -278,7 +292,7 @@ def main() -> int:
                                   "frac": round(13 * W * H * B / (integral_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "stump_evals_per_window": round(counted.stump_evals / max(counted.windows, 1), 3),
             "cascade_algorithmic_GBps": round(counted.gather_bytes / (cascade_ms / K * 1e-3) / 1e9, 2),
-            "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
+            "roofline": roofline, "kernels": per_kernel, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
             "cpu_baseline_opencvlike": cpu_cv, "opencv_profile": cv_profile, "parity_sample_ok": parity,
         }
     if world > 1:
