@@ -145,6 +145,7 @@ struct CascadeArgs {
     uint32_t  tile_sp_begin;                // >= number of stages: disabled
     uint32_t  tile_sp_pad;                  // dwords of LDS reserved for the finish: two record blocks + leaf values (0 = off)
     uint32_t  tile_sp_max;                  // enter the finish when at most this many windows are left
+    uint32_t  identity_order;               // StageDev::order is 0, 1, 2, ... (every linear cascade)
     uint32_t  n_seg;                        // stage tree: chains after the linear prefix that a tile may run itself (0: none)
     uint32_t  seg_end[4];                   // ... end position (sweep order) of chain k; it starts where chain k-1 (or the prefix) ends
     uint32_t  seg_chain;                    // ... bit k: the rejects of chain k are the population of chain k+1

@@ -680,6 +680,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.tile_repack_mask = e->tile_repack_mask;
         ca.tile_sp_begin = (pl->sp_pad || pl->tree2) ? (uint32_t)e->tile_sp_begin : 0xffffffffu;
         ca.tree2 = pl->tree2 ? 1u : 0u;
+        ca.identity_order = pl->general ? 0u : 1u;
         ca.n_seg = e->tile_segments ? pl->tile_n_seg : 0u;
         for (int k = 0; k < 4; ++k) ca.seg_end[k] = pl->tile_seg_end[k];
         ca.seg_chain = pl->tile_seg_chain;

@@ -467,7 +467,7 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
     kptr<StageDev> stages = as_k(a.stages);
     for (uint32_t pos = begin; pos < end && n != 0u; ++pos) {
         // [begin, end) are positions in the sweep order (StageDev::order); a linear cascade's order is 0, 1, 2, ...
-        const uint32_t s = stages[pos].order;
+        const uint32_t s = a.identity_order != 0u ? pos : stages[pos].order;   // (no dependent load for linear cascades)
         const uint32_t first_node = stages[s].first_node;
         const uint32_t n_nodes = stages[s].n_nodes;
         const float threshold = stages[s].threshold;
@@ -1090,7 +1090,7 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
     uint32_t pos = st_io;   // position in the sweep order (StageDev::order); a linear cascade's order is 0, 1, 2, ...
     // below tile_ws_min windows a chunk's lanes are mostly empty: the caller continues stump-parallel
     for (; pos < n_stages && T != 0u && T >= a.tile_ws_min; ++pos) {
-        const uint32_t s = stages[pos].order;
+        const uint32_t s = a.identity_order != 0u ? pos : stages[pos].order;   // (no dependent load for linear cascades)
         if (COUNT && threadIdx.x == 0) atomicAdd(a.stage_entered + s, (unsigned long long)T);
         // items of a stage: stumps, or two-node trees (TREE2: records 2t and 2t+1, a 2-bit leaf code per tree)
         constexpr uint32_t PER_WORD = TREE2 ? 16u : 32u;
