@@ -384,6 +384,11 @@ def test_config5_two_cascades_on_rois(env, oracle, cascades):
     assert env.detect_rois(ce, frames, np.zeros((0, 5), np.int32)).rects.size == 0
     with pytest.raises(Exception):
         env.detect_rois(ce, frames, [(0, 1270, 0, 40, 40)])          # outside the frame
+    # ROIs of BGR frames: the view starts at the ROI's first pixel, 3 bytes per pixel
+    col = np.repeat(frames[..., None], 3, 3)
+    got_c = env.detect_rois(ce, col, rois[:12], pe, color=True)
+    got_g = env.detect_rois(ce, frames, rois[:12], pe)
+    assert np.array_equal(got_c.rects, got_g.rects) and got_c.stage_entered == got_g.stage_entered
 
 
 def test_subbatching_and_detection_buffer_growth(env, cascades):

@@ -69,3 +69,24 @@ def test_refuses_stage_trees(env, cascades):
     c, _ = cascades("frontalface_alt_tree")
     with pytest.raises(Exception):
         env.detect_opencv(c, np.zeros((200, 200), np.uint8))
+
+
+def test_color_frames_subbatches_and_many_detections(env, oracle, cascades):
+    """BGR input goes through the same fused conversion as the clod profile; sub-batching (max_subbatch) and the
+    growth of the detection buffer (eye cascade on noise: tens of thousands of raw candidates) keep results equal."""
+    c, a = cascades("eye")
+    rng = np.random.default_rng(3)
+    gray = list(synth.batch(5, 300, 400, seed0=90, kinds=("blocks", "smooth")))
+    col = [np.repeat(g[..., None], 3, 2) for g in gray]                 # B = G = R: converts back to g exactly
+    base = env.detect_opencv(c, gray, flags=VJ_FLAG_COUNTERS)
+    assert len(base.rects) > 100
+    r = env.detect_opencv(c, col, flags=VJ_FLAG_COUNTERS, color=True)
+    assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
+    try:
+        env.configure("max_subbatch", 2)
+        r2 = env.detect_opencv(c, gray, flags=VJ_FLAG_COUNTERS)
+        assert np.array_equal(r2.rects, base.rects) and r2.stage_entered == base.stage_entered and r2.windows == base.windows
+    finally:
+        env.configure("max_subbatch", 0)
+    ro, st = oracle.detect_opencvlike(a, gray[0])
+    assert sorted(rows(base.rects[base.rects["frame"] == 0])) == sorted(rows(ro))
