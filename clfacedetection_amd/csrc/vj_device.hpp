@@ -86,7 +86,8 @@ struct SpBlock {
 };
 
 constexpr int UNIT_WINDOWS = 512;   // windows per wave-unit == per-wave LDS queue capacity
-constexpr int WAVES_PER_BLOCK = 4;
+constexpr int WAVES_PER_BLOCK = 3;    // waves per workgroup of the global-gather kernels: with one workgroup per CU next to the tile
+                                      // chain, 2 starve the gather chain (+12 ms), 4 slow the tiles (+1.5 ms); measured
 constexpr int MAX_SCALES = 128;
 constexpr int MAX_PASSES = 8;         // == VJ_MAX_PASSES
 constexpr uint32_t Q_PARTS = 8;       // parts of a scale's survivor-queue segment, by frame group (one per XCD to drain)

@@ -42,24 +42,23 @@ uint32_t frame_elems_for(int W, int H) {
 // Default pass split: stage boundaries after which the survivor population is small
 // enough that re-packing it across the whole chip pays for the extra launch.
 static std::vector<uint32_t> default_pass_bounds(const vj_cascade& c, const StageProgram& prog,
-                                                 const std::vector<int>& override_) {
+                                                 const std::vector<int>& override_, const std::vector<int>& cut_nodes) {
     const uint32_t n = (uint32_t)c.stages.size();
     std::vector<uint32_t> b{0};
     if (!override_.empty()) {
         for (int v : override_)
             if (v > (int)b.back() && v < (int)n) b.push_back((uint32_t)v);
     } else {
-        // cut after roughly 110 and 250 cumulative nodes (frontalface_alt: 5 | 8), measured best on 1080p
-        // batches: [0,5) global first pass, then two re-packed queue passes, all on the global-gather chain
-        // while the tile chain runs the whole cascade next to it
-        const uint32_t cuts[2] = {110, 250};
+        // cuts after given numbers of cumulative nodes (default: one, after ~150 — frontalface_alt: before stage 6 —
+        // measured best on 1080p batches: [0,6) global first pass, one re-packed queue pass for the rest, both on
+        // the global-gather chain while the tile chain runs the whole cascade next to it)
         uint32_t acc = 0;
-        int ci = 0;
-        for (uint32_t s = 0; s < n && ci < 2; ++s) {
+        size_t ci = 0;
+        for (uint32_t s = 0; s < n && ci < cut_nodes.size(); ++s) {
             acc += prog.n_nodes[s];
-            if (acc >= cuts[ci] && s + 1 < n) {
+            if (acc >= (uint32_t)cut_nodes[ci] && s + 1 < n) {
                 b.push_back(s + 1);
-                ++ci;
+                while (ci < cut_nodes.size() && acc >= (uint32_t)cut_nodes[ci]) ++ci;
             }
         }
     }
@@ -333,7 +332,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                 pl->units.push_back(UnitDev{slot, f, std::min<uint32_t>(UNIT_WINDOWS, sd.nwin - f), 0});
         }
     }
-    pl->pass_bounds = default_pass_bounds(c, pl->prog, e->split_override);
+    pl->pass_bounds = default_pass_bounds(c, pl->prog, e->split_override, e->pass_cut_nodes);
     if (pl->general) {   // positions in StageDev::order: [linear prefix | the rest]
         if (pl->general_prefix) pl->pass_bounds = {0u, pl->general_prefix, pl->n_order};
         else pl->pass_bounds = {0u, pl->n_order};
@@ -1023,6 +1022,23 @@ static void drop_plans(vj_env* e) {
 int vj_env_configure(vj_env* e, const char* key, const char* value) {
     if (!e || !key || !value) return VJ_ERR_ARG;
     HIP_TRY(hipSetDevice(e->device));
+    if (strcmp(key, "pass_cut_nodes") == 0) {   // default pass cuts: after these numbers of cumulative nodes
+        std::vector<int> v;
+        for (const char* q = value; *q;) {
+            char* end = nullptr;
+            const long x = strtol(q, &end, 10);
+            if (end == q) {
+                set_error("pass_cut_nodes: expected comma-separated integers, got '%s'", value);
+                return VJ_ERR_ARG;
+            }
+            v.push_back((int)x);
+            q = *end == ',' ? end + 1 : end;
+        }
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        e->pass_cut_nodes = v;
+        drop_plans(e);
+        return VJ_OK;
+    }
     if (strcmp(key, "pass_split") == 0) {
         std::vector<int> v;
         for (const char* q = value; *q;) {

@@ -108,7 +108,7 @@ struct vj_env {
     int grid_block_w = 32;              // width of the 2-D window blocks of the global-gather first pass (0: row runs)
     int global_blocks = 0;              // 1: large scales run as unstaged 2-D blocks in the tile kernel (stump cascades): 2.2x
                                         // faster than grid + queue passes on its own, but it overlaps the tile chain badly
-    int tile_lds_reserve_kb = 18;       // LDS per CU the tile classes leave to the other chain
+    int tile_lds_reserve_kb = 14;       // LDS per CU the tile classes leave to the other chain (its 3-wave workgroup: 12 KiB)
     char name[256] = "";
     int n_cu = 0;
     // image buffers
@@ -139,6 +139,7 @@ struct vj_env {
     int tile_ws_min = 48;         // ... below this many the stump-parallel finish takes over
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales
     std::vector<int> split_override;
+    std::vector<int> pass_cut_nodes{150};   // default pass cuts, in cumulative nodes
 };
 
 namespace vj {
