@@ -36,7 +36,8 @@ struct ScaleDev {
                            // first, odd columns from element tile_half on (window origins are all even, so a
                            // wave's gathers of one corner touch CONSECUTIVE dwords: no bank conflicts)
     int32_t  te_dw;        // equ_rect left->right distance in tile elements (signed when de-interleaved)
-    uint32_t pad[7];
+    uint32_t tile_x4;      // rows are staged 16 bytes per lane (pitch is a multiple of 4 dwords)
+    uint32_t pad[6];
 };
 static_assert(sizeof(ScaleDev) == 128, "ScaleDev is 128 bytes");
 

@@ -216,8 +216,17 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                     for (uint32_t th : kTh) {
                         const uint32_t nwt = tw * th;
                         if (nwt > TILE_WAVES * TILE_WAVE_CAP || nwt < 64 || nwt <= best_n) continue;
-                        const uint32_t pitch =
-                            ((uint32_t)std::ceil((double)(tw - 1) * (double)si.step) + 3u + reach_x) | 1u;  // odd pitch
+                        // rows staged 16 bytes per lane (tile_stage_x4; not the de-interleaved step-2 tiles, whose
+                        // sources are 8 bytes apart): pitch a multiple of 4 dwords, not of 32 (rows would share banks);
+                        // otherwise an odd pitch
+                        const bool x4 = e->tile_stage_x4 && !(e->tile_deinterleave && si.step == 2.0f);
+                        uint32_t pitch = (uint32_t)std::ceil((double)(tw - 1) * (double)si.step) + 3u + reach_x;
+                        if (x4) {
+                            pitch = (pitch + 3u) & ~3u;
+                            if (pitch % 32u == 0u) pitch += 4u;
+                        } else {
+                            pitch |= 1u;
+                        }
                         const uint32_t rows = (uint32_t)std::ceil((double)(th - 1) * (double)si.step) + 3u + reach_y;
                         if ((uint64_t)pitch * rows * 4u > budget) continue;
                         // staging a tile must stay far cheaper than gathering its windows from L2
@@ -239,6 +248,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
             table.resize(table.size() + n_nodes);
             // step exactly 2: every window origin is an even column -> de-interleave the tile rows
             sd.tile_half = (e->tile_deinterleave && si.step == 2.0f) ? (sd.tile_pitch + 1u) / 2u : 0u;
+            sd.tile_x4 = (e->tile_stage_x4 && !sd.tile_half && sd.tile_pitch % 4u == 0u) ? 1u : 0u;
             rc = build_node_table_stride(c, sd.tile_pitch, si, table.data() + sd.tile_table_first, sd.tile_half);
             if (rc) return rc;
             auto col = [&](uint32_t cx) { return sd.tile_half ? (cx & 1u) * sd.tile_half + (cx >> 1) : cx; };
@@ -1087,6 +1097,12 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "tile_sp_max") == 0) {
         e->tile_sp_max = std::max(0, std::min(atoi(value), (int)TILE_SP_MAX_WINDOWS));
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_stage_x4") == 0) {
+        e->tile_stage_x4 = atoi(value) != 0;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
         return VJ_OK;
     }
     if (strcmp(key, "tile_deinterleave") == 0) {

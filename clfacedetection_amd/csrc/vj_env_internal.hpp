@@ -137,6 +137,7 @@ struct vj_env {
     int tile_finish = 1;          // 0: stump-parallel finish, 1: wave-split finish
     int tile_ws_max = 512;        // windows a tile may carry into the wave-split finish
     int tile_ws_min = 48;         // ... below this many the stump-parallel finish takes over
+    int tile_stage_x4 = 1;        // stage tile rows with 16-byte LDS-DMA loads (4x fewer texture-address instructions)
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales
     std::vector<int> split_override;
     std::vector<int> pass_cut_nodes{150};   // default pass cuts, in cumulative nodes

@@ -1312,9 +1312,20 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         // straight into LDS (buffer_load ... lds: no VGPR round trip, so every load of the tile is in
         // flight at once instead of one load-wait-store per 256 bytes); the barrier drains them
         const uint32_t half = STAGED ? scales[slot].tile_half : 0u;
+        const uint32_t x4 = STAGED ? scales[slot].tile_x4 : 0u;
         for (uint32_t rr = wib; STAGED && rr < rows; rr += TILE_WAVES) {
             const uint32_t g_row = ((y0 + rr) * a.stride + x0) * 4u;   // uniform
-            if (half == 0u) {
+            if (half == 0u && x4 != 0u) {
+                // 16 bytes per lane, 1 KiB per instruction: a quarter of the texture-address work of the dword form
+                // (which the global-gather chain on the same CU is competing for)
+                for (uint32_t c0 = 0; c0 < pitch; c0 += 256u) {
+                    const uint32_t soff = __builtin_amdgcn_readfirstlane(g_row + c0 * 4u);
+                    if (c0 + lane * 4u < pitch)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(
+                            sum_f, (__attribute__((address_space(3))) uint32_t*)(lds_img + rr * pitch + c0), 16,
+                            lane * 16u, soff, 0, 0);
+                }
+            } else if (half == 0u) {
                 for (uint32_t c0 = 0; c0 < pitch; c0 += 64u) {
                     const uint32_t soff = __builtin_amdgcn_readfirstlane(g_row + c0 * 4u);   // keep it scalar
                     if (c0 + lane < pitch)

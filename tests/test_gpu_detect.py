@@ -120,10 +120,13 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
             r = env.detect(c, frames, p)
             assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, b
         env.configure("blocks_per_cu", 8)
-        env.configure("tile_deinterleave", 0)
-        r = env.detect(c, frames, p)
-        assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
+        for de, x4 in ((0, 1), (0, 0), (1, 0)):
+            env.configure("tile_deinterleave", de)
+            env.configure("tile_stage_x4", x4)
+            r = env.detect(c, frames, p)
+            assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, (de, x4)
         env.configure("tile_deinterleave", 1)
+        env.configure("tile_stage_x4", 1)
         for conc, reserve, blocks, split, gbw in ((0, 26, 1, 0, 32), (0, 0, 0, 0.4, 0), (1, 0, 1, 1.3, 32), (1, 40, 0, 2.5, 16),
                                                   (1, 26, 0, 0.7, 64), (1, 26, 0, 99, 32)):
             env.configure("concurrent", conc)
