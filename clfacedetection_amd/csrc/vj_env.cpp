@@ -772,7 +772,8 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             HIP_TRY(hipEventRecord(e->pass_ev[0], e->stream));
             // chain A: tile launches
             auto chain_a = [&]() -> int {
-            for (uint32_t cls = 0; cls < TILE_CLASSES && !hrc && ca.n_tile_units > 0; ++cls) {
+            for (uint32_t ci = 0; ci < TILE_CLASSES && !hrc && ca.n_tile_units > 0; ++ci) {
+                const uint32_t cls = e->tile_class_order ? TILE_CLASSES - 1u - ci : ci;
                 const uint32_t n_cls = pl->class_first[cls + 1] - pl->class_first[cls];
                 if (!n_cls) continue;
                 CascadeArgs ta = ca;
@@ -1097,6 +1098,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "tile_sp_max") == 0) {
         e->tile_sp_max = std::max(0, std::min(atoi(value), (int)TILE_SP_MAX_WINDOWS));
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_class_order") == 0) {
+        e->tile_class_order = atoi(value) != 0;
         return VJ_OK;
     }
     if (strcmp(key, "tile_stage_x4") == 0) {

@@ -137,6 +137,8 @@ struct vj_env {
     int tile_finish = 1;          // 0: stump-parallel finish, 1: wave-split finish
     int tile_ws_max = 512;        // windows a tile may carry into the wave-split finish
     int tile_ws_min = 48;         // ... below this many the stump-parallel finish takes over
+    int tile_class_order = 1;     // 1: launch the tile classes largest-LDS first (measured: 48.3 -> 47.2 ms; the one-workgroup-per-CU
+                                  // class suffers most from the gather chain, whose first pass is the heavier one)
     int tile_stage_x4 = 1;        // stage tile rows with 16-byte LDS-DMA loads (4x fewer texture-address instructions)
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales
     std::vector<int> split_override;
