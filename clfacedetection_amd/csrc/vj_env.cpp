@@ -210,7 +210,9 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
             for (uint32_t cls = 0; cls < TILE_CLASSES && best_n < (uint32_t)e->tile_min_windows; ++cls) {
                 const int kb = e->tile_class_kb[cls];
                 const uint32_t lds_cu = (160u - (uint32_t)e->tile_lds_reserve_kb) * 1024u;
-                const uint64_t budget = kb < 0 ? (lds_cu / (uint32_t)(-kb) - tile_header_bytes) & ~63ull
+                // (2 KiB of the CU's share stay free so that the nested class blocks below can be rounded up to whole
+                // allocation granules)
+                const uint64_t budget = kb < 0 ? ((lds_cu - 2048u) / (uint32_t)(-kb) - tile_header_bytes) & ~63ull
                                                : std::min<uint64_t>((uint64_t)kb * 1024u, 160u * 1024u - tile_header_bytes);
                 for (uint32_t tw : kTw)
                     for (uint32_t th : kTh) {
@@ -249,6 +251,11 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
             // step exactly 2: every window origin is an even column -> de-interleave the tile rows
             sd.tile_half = (e->tile_deinterleave && si.step == 2.0f) ? (sd.tile_pitch + 1u) / 2u : 0u;
             sd.tile_x4 = (e->tile_stage_x4 && !sd.tile_half && sd.tile_pitch % 4u == 0u) ? 1u : 0u;
+            if (getenv("VJ_DEBUG_PLAN"))
+                fprintf(stderr, "vj plan: scale %d s=%.3f step=%.2f nx=%u ny=%u class %u tile %ux%u = %u windows, pitch %u rows %u (%u B)%s%s\n",
+                        si.scale_idx, si.scale, si.step, sd.nx, sd.ny, sd.tile_class, sd.tile_tw, sd.tile_th, sd.tile_tw * sd.tile_th,
+                        sd.tile_pitch, sd.tile_rows, sd.tile_pitch * sd.tile_rows * 4u, sd.tile_half ? " deinterleaved" : "",
+                        sd.tile_x4 ? " x4" : "");
             rc = build_node_table_stride(c, sd.tile_pitch, si, table.data() + sd.tile_table_first, sd.tile_half);
             if (rc) return rc;
             auto col = [&](uint32_t cx) { return sd.tile_half ? (cx & 1u) * sd.tile_half + (cx >> 1) : cx; };
@@ -427,6 +434,26 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         if (pl->class_lds[cls]) pl->class_lds[cls] += tile_header_bytes;
     }
     pl->class_first[TILE_CLASSES] = (uint32_t)pl->tile_units.size();
+    // Nest the LDS blocks of consecutive classes: the tile launches follow each other on CUs where the gather
+    // chain's workgroup holds a block somewhere in the middle of the LDS, so the k workgroups of one class have to
+    // fit exactly into the hole the workgroup(s) of the other class leave behind (measured: a class-0 pair 2 KB
+    // larger than the class-1 block it follows leaves one tile workgroup per CU idle, + 17 % on that launch).
+    if (e->tile_lds_nest) {
+        const uint32_t lds_cu = (160u - (uint32_t)e->tile_lds_reserve_kb) * 1024u;
+        for (uint32_t cls = 0; cls + 1 < TILE_CLASSES; ++cls) {
+            const int ka = e->tile_class_kb[cls], kb = e->tile_class_kb[cls + 1];
+            if (ka >= 0 || kb >= 0 || !pl->class_lds[cls] || !pl->class_lds[cls + 1]) continue;
+            const uint32_t na = (uint32_t)(-ka), nb = (uint32_t)(-kb);   // workgroups per CU: na > nb
+            if (na <= nb || na % nb != 0u) continue;
+            const uint32_t ratio = na / nb;
+            uint32_t big = std::max(pl->class_lds[cls + 1], ratio * pl->class_lds[cls]);
+            // whole allocation granules (the hardware hands LDS out in 512-byte granules; 1 KiB is safe)
+            big = (big + ratio * 1024u - 1u) / (ratio * 1024u) * (ratio * 1024u);
+            if ((uint64_t)big * nb > lds_cu) continue;
+            pl->class_lds[cls + 1] = big;
+            pl->class_lds[cls] = big / ratio;
+        }
+    }
     pl->block_first = (uint32_t)pl->tile_units.size();
     if (!pl->general && !pl->trees)
         for (uint32_t slot = 0; slot < pl->scales.size(); ++slot) {
@@ -905,6 +932,9 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         if (getenv("VJ_DEBUG_STAMPS")) {  // diagnostic build (-DVJ_STAMPS=1): phase cycle sums of the tile kernel
             const unsigned long long* se =
                 (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * q_counts + 2);
+            for (size_t l = 0; l < linfo.size(); ++l)
+                fprintf(stderr, "vj launch %zu kind %d class %d: max resident workgroups %llu\n", l, linfo[l].kind, linfo[l].lds_class,
+                        se[(1 + l) * VJ_MAX_STAGES + 39]);
             fprintf(stderr, "vj stamps:");
             for (int i = 40; i < 60; ++i) {
                 unsigned long long v = 0;
@@ -1098,6 +1128,12 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "tile_sp_max") == 0) {
         e->tile_sp_max = std::max(0, std::min(atoi(value), (int)TILE_SP_MAX_WINDOWS));
+        return VJ_OK;
+    }
+    if (strcmp(key, "tile_lds_nest") == 0) {
+        e->tile_lds_nest = atoi(value) != 0;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
         return VJ_OK;
     }
     if (strcmp(key, "tile_class_order") == 0) {

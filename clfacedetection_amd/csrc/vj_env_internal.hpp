@@ -108,7 +108,8 @@ struct vj_env {
     int grid_block_w = 32;              // width of the 2-D window blocks of the global-gather first pass (0: row runs)
     int global_blocks = 0;              // 1: large scales run as unstaged 2-D blocks in the tile kernel (stump cascades): 2.2x
                                         // faster than grid + queue passes on its own, but it overlaps the tile chain badly
-    int tile_lds_reserve_kb = 14;       // LDS per CU the tile classes leave to the other chain (its 3-wave workgroup: 12 KiB)
+    int tile_lds_reserve_kb = 16;       // LDS per CU the tile classes leave to the other chain (its 3-wave workgroup: 12 KiB + granule
+                                        // rounding; with 14 the CU's 160 KiB do not take two class-0 blocks next to it any more)
     char name[256] = "";
     int n_cu = 0;
     // image buffers
@@ -139,6 +140,7 @@ struct vj_env {
     int tile_ws_min = 48;         // ... below this many the stump-parallel finish takes over
     int tile_class_order = 1;     // 1: launch the tile classes largest-LDS first (measured: 48.3 -> 47.2 ms; the one-workgroup-per-CU
                                   // class suffers most from the gather chain, whose first pass is the heavier one)
+    int tile_lds_nest = 1;        // LDS blocks of consecutive tile classes nest (k blocks of one = one block of the next)
     int tile_stage_x4 = 1;        // stage tile rows with 16-byte LDS-DMA loads (4x fewer texture-address instructions)
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales
     std::vector<int> split_override;

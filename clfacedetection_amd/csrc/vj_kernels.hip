@@ -1258,6 +1258,10 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
 
 #define STAMP(ph) do { if (VJ_STAMPS && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(a.stage_entered + 40 + (ph), t_ - t_last); t_last = t_; } } while (0)
     unsigned long long t_last = __builtin_amdgcn_s_memtime();
+    if (VJ_STAMPS && threadIdx.x == 0) {   // diagnostic: how many workgroups of this launch are resident at once?
+        const unsigned long long v = atomicAdd(a.stage_entered + 38, 1ull) + 1ull;
+        atomicMax(a.stage_entered + 39, v);
+    }
     // Tiles are handed out dynamically: a workgroup that becomes resident late — e.g. because another kernel
     // holds part of the CU — simply finds fewer tickets left.  The (frame, tile) list is cut into eight
     // contiguous parts, one per XCD (blocks b and b + 8 share an XCD under the observed round-robin placement;
@@ -1557,6 +1561,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         __syncthreads();
         u = __builtin_amdgcn_readfirstlane(lds_cnt[TILE_WAVES + 8]);
     }
+    if (VJ_STAMPS && threadIdx.x == 0) atomicAdd(a.stage_entered + 38, ~0ull);
 }
 
 int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, bool staged, int n_blocks, void* stream_) {

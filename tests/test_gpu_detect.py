@@ -138,7 +138,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
             assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, (conc, reserve, blocks, split)
             assert [sum(l["stage_entered"][s] for l in r.launches) for s in range(len(r.stage_entered))] == r.stage_entered
         env.configure("concurrent", 1)
-        env.configure("tile_lds_reserve_kb", 14)
+        env.configure("tile_lds_reserve_kb", 16)
         env.configure("global_blocks", 0)
         env.configure("tile_split", 0.5)
         env.configure("grid_block_w", 32)
@@ -162,7 +162,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
                     (classes, tile_end, minw, split)
     finally:
         env.configure("concurrent", 1)
-        env.configure("tile_lds_reserve_kb", 14)
+        env.configure("tile_lds_reserve_kb", 16)
         env.configure("global_blocks", 0)
         env.configure("tile_split", 0.5)
         env.configure("grid_block_w", 32)
