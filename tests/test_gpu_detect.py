@@ -445,3 +445,29 @@ def test_color_frames_detect_like_their_gray(env, oracle, cascades):
         rr = env.detect(c, roi, default_params(), color=True)
         rg = env.detect(c, np.ascontiguousarray(want[0][5:250, 7:333]), default_params())
         assert np.array_equal(rr.rects, rg.rects)
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_randomized_parity(env, oracle, cascades, seed):
+    """Random frame sizes (odd widths, thin frames, frames barely larger than the window), cascades, frame kinds,
+    size limits and scale factors against the oracle — rectangles, per-stage counts and window counts."""
+    rng = np.random.default_rng(1000 + seed)
+    casc = ["frontalface_alt", "frontalface_default", "frontalface_alt2", "eye", "frontalface_alt_tree"][seed % 5]
+    c, a = cascades(casc)
+    w = int(rng.integers(c.info.win_w + 11, 1100))
+    h = int(rng.integers(c.info.win_h + 11, 700))
+    if seed % 7 == 3:
+        h = c.info.win_h + 12          # a strip: few window rows
+    kind = ["noise", "smooth", "blocks"][int(rng.integers(0, 3))]
+    img = make_frame(kind, 5000 + seed, h, w)
+    mn = (0, 0) if seed % 3 else (int(rng.integers(20, 60)),) * 2
+    mx = (0, 0) if seed % 4 else (int(rng.integers(80, 300)),) * 2
+    sf = [1.1, 1.2, 1.05, 1.3][seed % 4]
+    p = default_params(flags=VJ_FLAG_COUNTERS, min_w=mn[0], min_h=mn[1], max_w=mx[0], max_h=mx[1], scale_factor=sf)
+    r = env.detect(c, img, p)
+    ro, st = oracle.detect(a, img, min_size=mn, max_size=mx, scale_factor=sf)
+    assert as_list(r.rects) == as_list(ro), (casc, w, h, kind, mn, mx, sf)
+    assert r.stage_entered == st["stage_entered"] and r.windows == st["windows"]
+    # and in a batch with its mirror image (independent frames, queue parts by frame)
+    rb = env.detect(c, [img, img[:, ::-1], img], p)
+    assert as_list(rb.rects[rb.rects["frame"] == 0]) == as_list(ro) == as_list(rb.rects[rb.rects["frame"] == 2])
