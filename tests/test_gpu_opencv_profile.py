@@ -90,3 +90,21 @@ def test_color_frames_subbatches_and_many_detections(env, oracle, cascades):
         env.configure("max_subbatch", 0)
     ro, st = oracle.detect_opencvlike(a, gray[0])
     assert sorted(rows(base.rects[base.rects["frame"] == 0])) == sorted(rows(ro))
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_randomized_parity(env, oracle, cascades, seed):
+    """Random sizes, cascades, min sizes and scale factors: rectangles, visited windows and per-stage counts equal the
+    oracle's restatement."""
+    rng = np.random.default_rng(2000 + seed)
+    casc = ["frontalface_alt", "frontalface_default", "frontalface_alt2", "eye"][seed % 4]
+    c, a = cascades(casc)
+    w = int(rng.integers(c.info.win_w + 12, 800))
+    h = int(rng.integers(c.info.win_h + 12, 560))
+    img = make_frame(["noise", "smooth", "blocks"][seed % 3], 6000 + seed, h, w, oracle)
+    mn = (0, 0) if seed % 2 else (int(rng.integers(20, 70)),) * 2
+    sf = [1.1, 1.25, 1.07][seed % 3]
+    r = env.detect_opencv(c, img, min_size=mn, scale_factor=sf, flags=VJ_FLAG_COUNTERS)
+    ro, st = oracle.detect_opencvlike(a, img, min_size=mn, scale_factor=sf)
+    assert sorted(rows(r.rects)) == sorted(rows(ro)), (casc, w, h, mn, sf)
+    assert r.windows == st["windows"] and r.stage_entered == st["stage_entered"]
