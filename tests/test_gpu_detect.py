@@ -471,3 +471,20 @@ def test_randomized_parity(env, oracle, cascades, seed):
     # and in a batch with its mirror image (independent frames, queue parts by frame)
     rb = env.detect(c, [img, img[:, ::-1], img], p)
     assert as_list(rb.rects[rb.rects["frame"] == 0]) == as_list(ro) == as_list(rb.rects[rb.rects["frame"] == 2])
+
+
+def test_reserve_then_detect_other_sizes(oracle, cascades):
+    """clodInitBuffers (vj_env_reserve) pre-sizes the device buffers; detection on smaller and on larger frames
+    afterwards — the zeroed slack rows belong to a layout, not to a buffer — still matches the oracle."""
+    from clfacedetection_amd import clodInitBuffers, clodInitEnvironment, clodReleaseEnvironment
+    c, a = cascades("frontalface_alt")
+    env2 = clodInitEnvironment(0)
+    try:
+        clodInitBuffers(env2, (640, 480), 2)
+        for h, w in ((240, 320), (480, 640), (300, 900), (240, 320)):
+            img = make_frame("noise", h + w, h, w)
+            r = env2.detect(c, [img, img[::-1].copy()], default_params(flags=VJ_FLAG_COUNTERS))
+            ro, st = oracle.detect(a, img)
+            assert as_list(r.rects[r.rects["frame"] == 0]) == as_list(ro)
+    finally:
+        clodReleaseEnvironment(env2)
