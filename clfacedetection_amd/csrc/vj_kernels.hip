@@ -786,22 +786,25 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
 
 
 // ------------------------------------------------------------------ LDS-tile pass
-// First pass for the dense small scales.  A workgroup of TILE_WAVES waves owns a tile of
-// 64 x (TILE_WAVES * rw) windows: it stages the tile's footprint of the sum image in LDS
-// with coalesced row loads, then every wave runs the usual compacting stage sweep over
-// its rw rows of windows — but gathers the rectangle corners from LDS instead of
-// through the texture-address unit.  Survivors leave through the same global queues
-// as the global-gather pass, as {global byte offset, variance}.
+// The whole cascade for the dense small scales (cascade_tile_pass, below).  A workgroup of TILE_WAVES waves owns
+// a tile of up to TILE_WAVES * TILE_WAVE_CAP windows: it stages the tile's footprint of the sum image in LDS, every
+// wave runs the compacting stage sweep over its share of the windows with the rectangle corners gathered from LDS
+// instead of through the texture-address unit, the waves pool their survivors before the later stages, and once
+// few windows are left the tile finishes the cascade with the two routines that follow.  What survives is a
+// detection; only a tile that stays crowded hands its windows to the global queues, as {global byte offset,
+// variance}.  The same kernel also runs unstaged (L2 gathers) on 2-D blocks of windows of the large scales.
 
 // Stump-parallel finish of a tile (stump cascades).  lds_q[0..T) holds the tile's T <= TILE_SP_MAX_WINDOWS
 // surviving windows.  Per stage, in blocks of <= 64 consecutive stumps: the block's node records are copied
-// to LDS field-major (the next block is prefetched into registers meanwhile); lane j owns stump j of the
-// block, wave w takes windows w, w + 8, ...; a (window, block) result is 64 bits — which stumps answered
-// alpha[1] — so one __ballot per window is all that is stored.  After the stage's last block, thread t walks
-// window t's bits IN STUMP ORDER and adds the leaf values (stage_sum += alpha[rect_sum >= norm_threshold],
-// clod.cl:81) — exactly the sequence of f32 additions a single lane would have made — compares with the
-// stage threshold, and the survivors are compacted across the waves.  Replaces the serial tail (one thin
-// wave, ~300 cycles per stump) of the late stages.
+// to LDS field-major (four blocks are prefetched into registers meanwhile); lane j owns stump j of the
+// block, wave w takes windows w, w + 8, ... two at a time; a (window, block) result is 64 verdict bits — which
+// stumps answered alpha[1], one __ballot — and the block's leaf sum (a DPP butterfly).  After the stage's last
+// block, thread t adds window t's block sums: when that clears the stage threshold by more than sp_delta (the
+// host's bound on the difference between any two summation orders) the stage is decided; otherwise the thread
+// walks the window's bits IN STUMP ORDER and adds the leaf values (stage_sum += alpha[rect_sum >=
+// norm_threshold], clod.cl:81) — exactly the sequence of f32 additions a single lane would have made.  The
+// survivors are compacted across the waves.  Replaces the serial tail (one thin wave, ~300 cycles per stump) of
+// the late stages; the wave-split finish (further down) takes the populations above tile_ws_min.
 template <bool COUNT, bool STAMPS = true, typename Img>
 __device__ __forceinline__ uint32_t tile_stump_parallel(const CascadeArgs& a, const Img& img_by_window,
                                                         const uint32_t* table /* the scale's tile table, global */,
