@@ -12,9 +12,10 @@ declared in include/vj.h, with numpy arrays standing in for IplImage / CvMat:
     clifIntegral(image, env)                     -> (sum, square_sum)
     clodReleaseBuffers(env); clodReleaseEnvironment(env)
 
-There is no CPU path here: `use_opencl=False` (the reference's CPU variants) raises,
-and a missing/unbuildable libvjhip.so or a missing GPU raises VjError — nothing in this
-package falls back to the oracle or to numpy.
+There is no CPU path here: `use_opencl=False` selects the WINDOW SET of the reference's
+CPU variants (their skip after a stage-0 reject), still evaluated on the device, and a
+missing/unbuildable libvjhip.so or a missing GPU raises VjError — nothing in this package
+falls back to the oracle or to numpy.
 """
 from __future__ import annotations
 
@@ -29,6 +30,8 @@ from .build import LIB_PATH, build_lib
 VJ_MAX_STAGES = 64
 VJ_FLAG_COUNTERS = 1 << 0
 VJ_FLAG_SIGNED_MEAN = 1 << 1
+VJ_FLAG_SKIP_LIST = 1 << 2     # the CLOD_PER_STAGE_ITERATIONS CPU variant's skip over the flattened window list (clod.cpp:729-732)
+VJ_FLAG_SKIP_ROW = 1 << 3      # the plain CPU variant: round() positions, skip inside a row (clod.cpp:1409-1432)
 
 # clod_flags of the reference (clod.h:17-19).  They select among the reference's CPU
 # evaluators; the HIP path has one evaluator, so they are accepted and ignored.
@@ -119,6 +122,8 @@ _SIGNATURES = {
     "vj_cascade_load_xml": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "vj_cascade_load": (C.c_int, [C.c_char_p, C.POINTER(C.c_void_p)]),
     "vj_cascade_save": (C.c_int, [C.c_void_p, C.c_char_p]),
+    "vj_cascade_from_arrays": (C.c_int, [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_int,
+                                         C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "vj_cascade_free": (None, [C.c_void_p]),
     "vj_cascade_get_info": (C.c_int, [C.c_void_p, C.POINTER(CascadeInfo)]),
     "vj_cascade_stages": (C.c_void_p, [C.c_void_p]),
@@ -137,6 +142,17 @@ _SIGNATURES = {
     "vj_env_configure": (C.c_int, [C.c_void_p, C.c_char_p, C.c_char_p]),
     "vj_integral": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]),
     "vj_integral_image": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vj_integral_tilted": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p]),
+    "vj_grayscale": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]),
+    "vj_host_alloc": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "vj_host_free": (None, [C.c_void_p, C.c_void_p]),
+    "vj_detect_chain": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.POINTER(Params),
+                                  C.POINTER(Params), C.POINTER(_Result), C.POINTER(_Result)]),
+    "vj_stream_create": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.POINTER(Params),
+                                   C.POINTER(C.c_void_p)]),
+    "vj_stream_submit": (C.c_int, [C.c_void_p, C.POINTER(_Image), C.c_int]),
+    "vj_stream_collect": (C.c_int, [C.c_void_p, C.POINTER(_Result)]),
+    "vj_stream_destroy": (None, [C.c_void_p]),
     "vj_detect_rois": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.c_void_p, C.c_int, C.POINTER(Params),
                                  C.POINTER(_Result)]),
     "vj_detect_opencv": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(_Image), C.c_int, C.POINTER(CvParams),
@@ -214,6 +230,21 @@ class Cascade:
             return cls.load_xml(path)
         h = C.c_void_p()
         _check(load_library().vj_cascade_load(os.fsencode(path), C.byref(h)), f"vj_cascade_load({path})")
+        return cls(h.value)
+
+    @classmethod
+    def from_arrays(cls, win_w: int, win_h: int, stages: np.ndarray, trees: np.ndarray, nodes: np.ndarray,
+                    alpha: np.ndarray) -> "Cascade":
+        """vj_cascade_from_arrays: a cascade held in memory (STAGE_DTYPE / TREE_DTYPE / NODE_DTYPE arrays + f32 leaf values),
+        e.g. converted from a CvHaarClassifierCascade."""
+        st = np.ascontiguousarray(stages, STAGE_DTYPE)
+        tr = np.ascontiguousarray(trees, TREE_DTYPE)
+        nd = np.ascontiguousarray(nodes, NODE_DTYPE)
+        al = np.ascontiguousarray(alpha, np.float32)
+        h = C.c_void_p()
+        _check(load_library().vj_cascade_from_arrays(int(win_w), int(win_h), st.ctypes.data, len(st), tr.ctypes.data, len(tr),
+                                                     nd.ctypes.data, len(nd), al.ctypes.data, len(al), C.byref(h)),
+               "vj_cascade_from_arrays")
         return cls(h.value)
 
     def save(self, path: str):
@@ -328,6 +359,58 @@ class Environment:
                "vj_integral")
         return s, q
 
+    def _one_image(self, img: np.ndarray):
+        if img.dtype != np.uint8 or img.ndim not in (2, 3):
+            raise ValueError("expected a 2-D uint8 image or a (h, w, 3|4) uint8 BGR/BGRA image")
+        g = _pixel_contiguous(img) if img.ndim == 3 else (img if img.strides[1] == 1 else np.ascontiguousarray(img))
+        return _Image(g.ctypes.data, g.shape[1], g.shape[0], g.strides[0], 0, g.shape[2] if g.ndim == 3 else 1), g
+
+    def integral_tilted(self, img: np.ndarray) -> np.ndarray:
+        """vj_integral_tilted: cvIntegral's tilted sum, (h+1, w+1) uint32."""
+        im, keep = self._one_image(img)
+        t = np.empty((img.shape[0] + 1, img.shape[1] + 1), np.uint32)
+        _check(load_library().vj_integral_tilted(self._h, C.byref(im), t.ctypes.data), "vj_integral_tilted")
+        return t
+
+    def grayscale(self, img: np.ndarray) -> np.ndarray:
+        """clifGrayscale: the 8-bit gray image the integral kernels see (BGR / BGRA -> gray on the device)."""
+        im, keep = self._one_image(img)
+        g = np.empty(img.shape[:2], np.uint8)
+        _check(load_library().vj_grayscale(self._h, C.byref(im), g.ctypes.data, g.strides[0]), "vj_grayscale")
+        return g
+
+    def host_alloc(self, shape, dtype=np.uint8) -> np.ndarray:
+        """vj_host_alloc: a page-locked numpy array (freed with host_free) for copy-free frame uploads."""
+        n = int(np.prod(shape)) * np.dtype(dtype).itemsize
+        ptr = C.c_void_p()
+        _check(load_library().vj_host_alloc(self._h, n, C.byref(ptr)), "vj_host_alloc")
+        buf = (C.c_char * n).from_address(ptr.value)
+        arr = np.frombuffer(buf, dtype).reshape(shape)
+        self.__dict__.setdefault("_pinned", {})[arr.ctypes.data] = ptr.value
+        return arr
+
+    def host_free(self, arr: np.ndarray):
+        ptr = self.__dict__.get("_pinned", {}).pop(arr.ctypes.data, None)
+        if ptr is not None:
+            load_library().vj_host_free(self._h, C.c_void_p(ptr))
+
+    def detect_chain(self, first: Cascade, second: Cascade, frames, params_first: Params | None = None,
+                     params_second: Params | None = None, color: bool = False):
+        """vj_detect_chain: `second` on every raw candidate of `first`, hand-off on the device.  Returns (result_first,
+        result_second); result_second.rects['frame'] indexes result_first.rects, x / y are relative to that region."""
+        p1 = params_first or default_params()
+        p2 = params_second or default_params()
+        imgs, n, keep = self._images(frames, color)
+        r1, r2 = _Result(), _Result()
+        lib = load_library()
+        _check(lib.vj_detect_chain(self._h, first._h, second._h, imgs, n, C.byref(p1), C.byref(p2), C.byref(r1), C.byref(r2)),
+               "vj_detect_chain")
+        return self._result(lib, r1, first), self._result(lib, r2, second)
+
+    def stream(self, cascade: Cascade, width: int, height: int, max_batch: int, params: Params | None = None,
+               channels: int = 1) -> "FrameStream":
+        return FrameStream(self, cascade, width, height, max_batch, params or default_params(), channels)
+
     @staticmethod
     def _images(frames, color: bool):
         """-> (ctypes array of vj_image, n, arrays to keep alive)"""
@@ -429,6 +512,42 @@ class Environment:
             pass
 
 
+class FrameStream:
+    """vj_stream: double-buffered upload of host frame batches overlapped with the previous batch's kernels."""
+
+    def __init__(self, env: Environment, cascade: Cascade, width: int, height: int, max_batch: int, params: Params, channels: int = 1):
+        self._env, self._cascade = env, cascade
+        h = C.c_void_p()
+        _check(load_library().vj_stream_create(env._h, cascade._h, width, height, channels, max_batch, C.byref(params), C.byref(h)),
+               "vj_stream_create")
+        self._h = h
+        self._keep = []
+
+    def submit(self, frames, color: bool = False):
+        imgs, n, keep = Environment._images(frames, color)
+        _check(load_library().vj_stream_submit(self._h, imgs, n), "vj_stream_submit")
+        self._keep.append((imgs, keep))
+
+    def collect(self) -> DetectResult:
+        res = _Result()
+        lib = load_library()
+        _check(lib.vj_stream_collect(self._h, C.byref(res)), "vj_stream_collect")
+        if self._keep:
+            self._keep.pop(0)
+        return Environment._result(lib, res, self._cascade)
+
+    def close(self):
+        if self._h:
+            load_library().vj_stream_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 @dataclass
 class DeviceFrames:
     """A batch of equal-size 8-bit frames already resident in device memory
@@ -502,8 +621,12 @@ def clodDetectObjects(image, cascade: Cascade, env: Environment, min_window_size
     """clod.h:72-81 / clod.cpp:1339-1356 with use_opencl=CL_TRUE → clodDetectObjectsOpenCL
     (clod.cpp:1176-1336).  `image` may also be a batch (see Environment.detect)."""
     if not use_opencl:
-        raise VjError(4, "clodDetectObjects", "use_opencl=False selects the reference's CPU evaluators; "
-                                              "this package implements the device path only")
+        # the reference's CPU evaluators (clod.cpp:1358-1499) return the skip-thinned window set; the device computes the
+        # same set for its two non-"block" loops.  The block variant (clod.cpp:821-1173) keeps `step` in double and is
+        # a third grid: not implemented.
+        if flags & CLOD_BLOCK_IMPLEMENTATION:
+            raise VjError(4, "clodDetectObjects", "CLOD_BLOCK_IMPLEMENTATION (f64 step, clod.cpp:862) is not implemented")
+        vj_flags |= VJ_FLAG_SKIP_LIST if flags & CLOD_PER_STAGE_ITERATIONS else VJ_FLAG_SKIP_ROW
     p = default_params(min_w=int(min_window_size[0]), min_h=int(min_window_size[1]),
                        max_w=int(max_window_size[0]), max_h=int(max_window_size[1]),
                        min_neighbors=int(min_neighbors), flags=int(vj_flags))

@@ -312,6 +312,37 @@ StageProgram build_stage_program(const vj_cascade& c) {
     return sp;
 }
 
+// Topological order of the pass / fail graph rooted at stage 0 (depth-first, pass edge first; reverse post-order):
+// a window's walk through the stage tree only ever moves forward in it.  Unreachable stages are dropped.
+bool stage_sweep_order(const StageProgram& prog, std::vector<uint32_t>* order) {
+    const int nS = (int)prog.on_pass.size();
+    std::vector<int> state(nS, 0);  // 0 unvisited, 1 on stack, 2 done
+    std::vector<uint32_t> post;
+    bool cyclic = false;
+    std::vector<std::pair<int, int>> stack{{0, 0}};
+    state[0] = 1;
+    while (!stack.empty()) {
+        auto& [s, phase] = stack.back();
+        if (phase < 2) {
+            const int nxt = phase == 0 ? prog.on_pass[s] : prog.on_fail[s];
+            ++phase;
+            if (nxt >= 0) {
+                if (state[nxt] == 1) cyclic = true;
+                if (state[nxt] == 0) {
+                    state[nxt] = 1;
+                    stack.push_back({nxt, 0});
+                }
+            }
+        } else {
+            state[s] = 2;
+            post.push_back((uint32_t)s);
+            stack.pop_back();
+        }
+    }
+    order->assign(post.rbegin(), post.rend());
+    return !cyclic;
+}
+
 }  // namespace vj
 
 // ------------------------------------------------------------------- C ABI
@@ -363,6 +394,48 @@ int vj_cascade_load_xml(const char* path, vj_cascade** out) {
 //   char magic[8] "VJCASC01"; u32 notice_len; char notice[notice_len padded to 4];
 //   i32 win_w, win_h, n_stages, n_trees, n_nodes, n_alpha;
 //   vj_stage_desc[n_stages]; vj_tree_desc[n_trees]; vj_node_desc[n_nodes]; f32[n_alpha]
+// Structural validation shared by every way a cascade gets in (indices are trusted by the table builders).
+static int validate_cascade(const vj_cascade& c, const char* what) {
+    const int nS = (int)c.stages.size(), nT = (int)c.trees.size(), nN = (int)c.nodes.size(), nA = (int)c.alpha.size();
+    if (c.win_w <= 0 || c.win_h <= 0 || c.win_w > 4096 || c.win_h > 4096 || nS <= 0 || nT <= 0 || nN <= 0 || nA <= 0) {
+        set_error("%s: empty cascade or bad window size", what);
+        return VJ_ERR_PARSE;
+    }
+    for (int i = 0; i < nS; ++i) {
+        const vj_stage_desc& s = c.stages[i];
+        // a parent precedes its child (icvReadHaarClassifier reads stages in order; the fail walk climbs parents)
+        if (s.first_tree < 0 || s.n_trees <= 0 || s.first_tree > nT - s.n_trees || s.parent < -1 || s.parent >= i ||
+            s.next < -1 || s.next >= nS || s.child < -1 || s.child >= nS) {
+            set_error("%s: stage links out of range", what);
+            return VJ_ERR_PARSE;
+        }
+    }
+    for (const auto& t : c.trees) {
+        if (t.first_node < 0 || t.n_nodes <= 0 || t.first_node > nN - t.n_nodes || t.first_alpha < 0 ||
+            t.n_nodes + 1 > nA || t.first_alpha > nA - t.n_nodes - 1) {
+            set_error("%s: tree links out of range", what);
+            return VJ_ERR_PARSE;
+        }
+        for (int k = 0; k < t.n_nodes; ++k) {
+            const vj_node_desc& n = c.nodes[t.first_node + k];
+            if (n.left >= t.n_nodes || n.right >= t.n_nodes || n.left < -t.n_nodes || n.right < -t.n_nodes ||
+                (n.left > 0 && n.left <= k) || (n.right > 0 && n.right <= k) || n.n_rects < 1 || n.n_rects > 3) {
+                set_error("%s: node links out of range", what);
+                return VJ_ERR_PARSE;
+            }
+            for (int q = 0; q < 3; ++q) {
+                const vj_rect_desc& r = n.rect[q];
+                if (r.x < 0 || r.y < 0 || r.w < 0 || r.h < 0 || r.x > 4096 || r.y > 4096 || r.w > 4096 || r.h > 4096 ||
+                    !(r.weight == r.weight)) {
+                    set_error("%s: node %d rect %d out of range", what, t.first_node + k, q);
+                    return VJ_ERR_PARSE;
+                }
+            }
+        }
+    }
+    return VJ_OK;
+}
+
 static const char kMagic[8] = {'V', 'J', 'C', 'A', 'S', 'C', '0', '1'};
 
 int vj_cascade_save(const vj_cascade* c, const char* path) {
@@ -426,35 +499,47 @@ int vj_cascade_load(const char* path, vj_cascade** out) {
     memcpy(c->nodes.data(), p, c->nodes.size() * sizeof(vj_node_desc));
     p += c->nodes.size() * sizeof(vj_node_desc);
     memcpy(c->alpha.data(), p, c->alpha.size() * sizeof(float));
-    // structural validation (indices are trusted by the table builder)
-    const int nS = hdr[2], nT = hdr[3], nN = hdr[4], nA = hdr[5];
-    for (const auto& s : c->stages)
-        if (s.first_tree < 0 || s.n_trees <= 0 || s.first_tree + s.n_trees > nT || s.parent < -1 || s.parent >= nS ||
-            s.next < -1 || s.next >= nS || s.child < -1 || s.child >= nS) {
-            set_error("%s: stage links out of range", path);
-            return VJ_ERR_PARSE;
-        }
-    for (const auto& t : c->trees) {
-        if (t.first_node < 0 || t.n_nodes <= 0 || t.first_node + t.n_nodes > nN || t.first_alpha < 0 ||
-            t.first_alpha + t.n_nodes + 1 > nA) {
-            set_error("%s: tree links out of range", path);
-            return VJ_ERR_PARSE;
-        }
-        for (int k = 0; k < t.n_nodes; ++k) {
-            const vj_node_desc& n = c->nodes[t.first_node + k];
-            if (n.left >= t.n_nodes || n.right >= t.n_nodes || -n.left > t.n_nodes || -n.right > t.n_nodes ||
-                (n.left > 0 && n.left <= k) || (n.right > 0 && n.right <= k) || n.n_rects < 1 || n.n_rects > 3) {
-                set_error("%s: node links out of range", path);
-                return VJ_ERR_PARSE;
-            }
-        }
-    }
+    if ((rc = validate_cascade(*c, path))) return rc;
     c->uid = g_uid++;
     *out = c.release();
     return VJ_OK;
 }
 
 void vj_cascade_free(vj_cascade* c) { delete c; }
+
+// A cascade the caller already holds in memory (the reference's caller has a CvHaarClassifierCascade* from
+// cvLoad, main.cpp:36; layout tempcv.hpp:70-112): the arrays are copied and validated like a file's.
+int vj_cascade_from_arrays(int win_w, int win_h, const vj_stage_desc* stages, int n_stages, const vj_tree_desc* trees,
+                           int n_trees, const vj_node_desc* nodes, int n_nodes, const float* alpha, int n_alpha,
+                           vj_cascade** out) {
+    if (!out) return VJ_ERR_ARG;
+    *out = nullptr;
+    if (!stages || !trees || !nodes || !alpha || n_stages <= 0 || n_trees <= 0 || n_nodes <= 0 || n_alpha <= 0 ||
+        n_stages > (1 << 24) || n_trees > (1 << 24) || n_nodes > (1 << 24) || n_alpha > (1 << 24))
+        return VJ_ERR_ARG;
+    auto c = std::make_unique<vj_cascade>();
+    c->win_w = win_w;
+    c->win_h = win_h;
+    c->stages.assign(stages, stages + n_stages);
+    c->trees.assign(trees, trees + n_trees);
+    c->nodes.assign(nodes, nodes + n_nodes);
+    c->alpha.assign(alpha, alpha + n_alpha);
+    // `child` as icvReadHaarClassifier derives it (tempcv.cpp:2080-2083) when the caller left it unset (all -1)
+    bool any_child = false;
+    for (const auto& s : c->stages) any_child |= s.child != -1;
+    if (!any_child) {
+        for (int i = 0; i < n_stages; ++i) {
+            const int pa = c->stages[i].parent;
+            if (pa >= 0 && pa < n_stages && c->stages[pa].child == -1) c->stages[pa].child = i;
+        }
+    }
+    int rc = validate_cascade(*c, "vj_cascade_from_arrays");
+    if (rc) return rc;
+    c->uid = g_uid++;
+    *out = c.release();
+    return VJ_OK;
+}
+
 
 int vj_cascade_get_info(const vj_cascade* c, vj_cascade_info* o) {
     if (!c || !o) return VJ_ERR_ARG;

@@ -5,7 +5,9 @@
 //                                        CV_ADJUST_WEIGHTS = 0; the "align blocks" flags can never be set:
 //                                        kx = r0.width / base_w >= 1)
 //   stage threshold bias               tempcv.cpp:262, 419
-// Linear cascades of stumps or multi-node trees; stage-tree cascades and tilted features are refused.
+//   hidden-cascade flags               tempcv.cpp:410-470 (isStumpBased, is_tree, per-stage two_rects) — they select
+//                                        the arithmetic of a node sum (vj_cv_profile.hip: cv_node_sum)
+// Stumps or multi-node trees, linear cascades or stage trees, upright or tilted features (tilted integral).
 // Second arithmetic profile.  OpenCV itself is not available here or on the GPU box, so
 // parity is against the oracle's restatement of the same lines (oc_detect_opencvlike): unpinned.
 #include "vj_env_internal.hpp"
@@ -59,20 +61,26 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
         return VJ_ERR_LIMIT;
     }
     const StageProgram prog = build_stage_program(*c);
-    bool trees = false;
-    for (size_t s = 0; s < c->stages.size(); ++s) {
-        const int32_t want_pass = s + 1 < c->stages.size() ? (int32_t)(s + 1) : (int32_t)STAGE_ACCEPT;
-        if (prog.on_pass[s] != want_pass || prog.on_fail[s] != STAGE_REJECT) {
-            set_error("the OpenCV profile runs linear cascades only (this one is a stage tree)");
-            return VJ_ERR_UNSUPPORTED;
-        }
+    std::vector<uint32_t> order;
+    if (!stage_sweep_order(prog, &order)) {
+        set_error("stage links form a cycle");
+        return VJ_ERR_UNSUPPORTED;
     }
+    // icvCreateHidHaarClassifierCascade's flags (tempcv.cpp:410-470)
+    bool trees = false, is_tree = false, has_tilted = false;
+    for (const auto& st : c->stages) is_tree |= st.next != -1;
     for (const auto& t : c->trees)
         if (t.n_nodes != 1) trees = true;
-    for (const auto& nd : c->nodes)
-        if (nd.tilted) {
-            set_error("tilted features are not supported");
-            return VJ_ERR_UNSUPPORTED;
+    for (const auto& nd : c->nodes) has_tilted |= nd.tilted != 0;
+    std::vector<uint8_t> two_rects(c->stages.size(), 1);
+    for (size_t s2 = 0; s2 < c->stages.size(); ++s2)
+        for (int t = 0; t < c->stages[s2].n_trees; ++t) {
+            const vj_tree_desc& td = c->trees[c->stages[s2].first_tree + t];
+            for (int l = 0; l < td.n_nodes; ++l) {
+                const vj_rect_desc& r2 = c->nodes[td.first_node + l].rect[2];
+                // :452-457: the third rectangle counts unless |weight| < DBL_EPSILON or it is empty
+                if (!(std::fabs((double)r2.weight) < 2.220446049250313e-16 || r2.w == 0 || r2.h == 0)) two_rects[s2] = 0;
+            }
         }
     HIP_TRY(hipSetDevice(e->device));
 
@@ -100,7 +108,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
     }
     const size_t n_nodes = c->nodes.size();
     std::vector<CvScaleDev> scales(hs.size());
-    std::vector<NodeRec> table(hs.size() * n_nodes);
+    std::vector<CvNodeRec> table(hs.size() * n_nodes);
     std::vector<UnitDev> rows;
     bool reach_ok = true;
     const uint32_t frame_elems = frame_elems_for(W, H);
@@ -124,41 +132,53 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
         sd.q3 = sd.q2 + (uint32_t)ew;
         sd.table_first = (uint32_t)(k * n_nodes);
         sd.scale_idx = (uint32_t)hs[k].idx;
-        NodeRec* recs = table.data() + k * n_nodes;
+        CvNodeRec* recs = table.data() + k * n_nodes;
         for (size_t t = 0; t < c->trees.size(); ++t) {
             const vj_tree_desc& td = c->trees[t];
             for (int j = 0; j < td.n_nodes; ++j) {
                 const vj_node_desc& nd = c->nodes[td.first_node + j];
-                NodeRec& r = recs[td.first_node + j];
+                CvNodeRec& r = recs[td.first_node + j];
                 memset(&r, 0, sizeof(r));
                 if (nd.rect[0].weight == 0.0f || nd.rect[1].weight == 0.0f) {
                     set_error("node %d: rect 0 and rect 1 must both be weighted", td.first_node + j);
                     return VJ_ERR_UNSUPPORTED;
                 }
                 double sum0 = 0, area0 = 0;
-                uint32_t dw[3] = {0, 0, 0};
+                const double correction_ratio = weight_scale * (!nd.tilted ? 1 : 0.5);   // :731
                 for (int q = 0; q < 3; ++q) {
-                    if (nd.rect[q].weight == 0.0f) break;   // hidfeature->rect[k].p0 == 0 ends the list (tempcv.cpp:663)
+                    // hidfeature->rect[k].p0 == 0 ends the list (tempcv.cpp:663): only a third rectangle can be absent (:452-455)
+                    if (q == 2 && (std::fabs((double)nd.rect[2].weight) < 2.220446049250313e-16 || nd.rect[2].w == 0 || nd.rect[2].h == 0))
+                        break;
                     const int tx = cv_round(nd.rect[q].x * scale), ty = cv_round(nd.rect[q].y * scale);
                     const int tw = cv_round(nd.rect[q].w * scale), th = cv_round(nd.rect[q].h * scale);
-                    const uint64_t lt = ((uint64_t)ty * stride + (uint64_t)tx) * 4u, dh = (uint64_t)th * stride * 4u;
-                    if (lt > 0xffffffffull || dh > 0xffffffffull || tw * 4 > 32767) {
+                    // corners p0, p1 = p0 + da, p2 = p0 + db, p3 = p0 + da + db (element offsets)
+                    const int64_t p0 = (int64_t)ty * stride + tx;
+                    int64_t da, db;
+                    if (!nd.tilted) {         // :735-741
+                        da = tw;
+                        db = (int64_t)th * stride;
+                    } else {                  // :743-750: p1 = (y + h, x - h), p2 = (y + w, x + w), p3 = (y + w + h, x + w - h)
+                        da = (int64_t)th * stride - th;
+                        db = (int64_t)tw * stride + tw;
+                    }
+                    if (p0 < 0 || da < 0 || db < 0 || (p0 + da + db) * 4 > 0x7fffffffll) {
                         set_error("feature offsets exceed the device record range");
                         return VJ_ERR_LIMIT;
                     }
-                    r.lt[q] = (uint32_t)lt;
-                    r.dh[q] = (uint32_t)dh;
-                    dw[q] = (uint32_t)(tw * 4);
-                    r.w[q] = (float)(nd.rect[q].weight * weight_scale);    // correction_ratio = weight_scale (:731)
+                    r.lt[q] = (uint32_t)(p0 * 4);
+                    r.da[q] = (uint32_t)(da * 4);
+                    r.db[q] = (uint32_t)(db * 4);
+                    r.w[q] = (float)(nd.rect[q].weight * correction_ratio);
                     if (q == 0)
                         area0 = tw * th;
                     else
                         sum0 += r.w[q] * tw * th;                          // float * int * int, added to a double (:756)
-                    max_reach = std::max<uint64_t>(max_reach, (uint64_t)(ty + th) * stride + (uint64_t)(tx + tw));
+                    max_reach = std::max<uint64_t>(max_reach, (uint64_t)(p0 + da + db));
+                    max_reach = std::max<uint64_t>(max_reach, (uint64_t)(p0 + db));
                 }
                 r.w[0] = (float)(-sum0 / area0);
                 r.thr = nd.threshold;
-                uint32_t flags = 0;
+                uint32_t flags = nd.tilted ? CV_NODE_TILTED : 0u;
                 auto leaf_or_node = [&](int v, uint32_t flag, uint32_t* dst) {
                     if (v > 0) {
                         flags |= flag;
@@ -171,8 +191,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 leaf_or_node(nd.left, NODE_LEFT_IS_NODE, &r.left);
                 leaf_or_node(nd.right, NODE_RIGHT_IS_NODE, &r.right);
                 if (j == td.n_nodes - 1) flags |= NODE_TREE_LAST;
-                r.dw01 = dw[0] | (dw[1] << 16);
-                r.dw2_flags = dw[2] | (flags << 16);
+                r.flags = flags;
             }
         }
         // evaluated windows satisfy x + win_w <= W and y + win_h <= H (border rule); a feature may overshoot its
@@ -188,6 +207,11 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
         stages[s].n_nodes = prog.n_nodes[s];
         stages[s].threshold = c->stages[s].threshold - 0.0001f;   // icv_stage_threshold_bias, in f32
         stages[s].n_trees = (uint32_t)c->stages[s].n_trees;
+        stages[s].on_pass = prog.on_pass[s];
+        stages[s].on_fail = prog.on_fail[s];
+        stages[s].order = s < order.size() ? order[s] : 0u;
+        // an f64 product per rectangle only on cvRunHaarClassifierCascadeSum's stump path (:863-888)
+        stages[s].cv_f64 = (two_rects[s] && !trees && !is_tree) ? 1u : 0u;
     }
     if (!reach_ok) {
         set_error("feature reach exceeds the frame allocation");
@@ -200,13 +224,13 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
         ~Releaser() { for (DevBuf* x : b) x->release(); }
     } releaser{{&d_table, &d_scales, &d_stages, &d_rows, &d_det, &d_counts}};
     int rc;
-    if ((rc = d_table.ensure(std::max<size_t>(table.size(), 1) * sizeof(NodeRec)))) return rc;
+    if ((rc = d_table.ensure(std::max<size_t>(table.size(), 1) * sizeof(CvNodeRec)))) return rc;
     if ((rc = d_scales.ensure(std::max<size_t>(scales.size(), 1) * sizeof(CvScaleDev)))) return rc;
     if ((rc = d_stages.ensure(stages.size() * sizeof(StageDev)))) return rc;
     if ((rc = d_rows.ensure(std::max<size_t>(rows.size(), 1) * sizeof(UnitDev)))) return rc;
     const size_t counts_bytes = 2 * VJ_MAX_STAGES * sizeof(uint64_t) + 16;
     if ((rc = d_counts.ensure(counts_bytes))) return rc;
-    if (!table.empty()) HIP_TRY(hipMemcpy(d_table.p, table.data(), table.size() * sizeof(NodeRec), hipMemcpyHostToDevice));
+    if (!table.empty()) HIP_TRY(hipMemcpy(d_table.p, table.data(), table.size() * sizeof(CvNodeRec), hipMemcpyHostToDevice));
     if (!scales.empty()) HIP_TRY(hipMemcpy(d_scales.p, scales.data(), scales.size() * sizeof(CvScaleDev), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(d_stages.p, stages.data(), stages.size() * sizeof(StageDev), hipMemcpyHostToDevice));
     if (!rows.empty()) HIP_TRY(hipMemcpy(d_rows.p, rows.data(), rows.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
@@ -224,9 +248,10 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
         size_t gray_frame_bytes;
         int gray_stride;
         if ((rc = stage_frames(e, frames + f0, nf, W, H, &d_gray, &gray_frame_bytes, &gray_stride))) return rc;
-        HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+        HIP_TRY(hipEventRecord(e->lane0.ev[0], e->stream));
         if ((rc = enqueue_integral(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf, CH))) return rc;
-        HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+        if (has_tilted && (rc = enqueue_tilted(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf, CH))) return rc;
+        HIP_TRY(hipEventRecord(e->lane0.ev[1], e->stream));
         for (int attempt = 0; attempt < 2; ++attempt) {
             if ((rc = d_det.ensure((size_t)det_cap * sizeof(CvDet)))) return rc;
             HIP_TRY(hipMemsetAsync(d_counts.p, 0, counts_bytes, e->stream));
@@ -234,6 +259,8 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             memset(&a, 0, sizeof(a));
             a.sum = (const uint32_t*)e->d_sum.p;
             a.sqsum = (const uint64_t*)e->d_sqsum.p;
+            a.tilted = has_tilted ? (const uint32_t*)e->d_tilted.p : nullptr;
+            a.n_order = (uint32_t)order.size();
             a.table = (const uint32_t*)d_table.p;
             a.scales = (const CvScaleDev*)d_scales.p;
             a.stages = (const StageDev*)d_stages.p;
@@ -250,13 +277,13 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             a.det_count = (uint32_t*)((unsigned long long*)d_counts.p + 2 * VJ_MAX_STAGES);
             a.det_cap = det_cap;
             a.stage_entered = (unsigned long long*)d_counts.p;
-            HIP_TRY(hipEventRecord(e->ev[2], e->stream));
-            const int hrc = launch_cv_profile_pass(a, trees, count, n_blocks, e->stream);
+            HIP_TRY(hipEventRecord(e->lane0.ev[2], e->stream));
+            const int hrc = launch_cv_profile_pass(a, trees, count, is_tree, n_blocks, e->stream);
             if (hrc) {
                 set_error("cascade launch failed: %s", hipGetErrorString((hipError_t)hrc));
                 return VJ_ERR_HIP;
             }
-            HIP_TRY(hipEventRecord(e->ev[3], e->stream));
+            HIP_TRY(hipEventRecord(e->lane0.ev[3], e->stream));
             std::vector<unsigned long long> h(2 * VJ_MAX_STAGES + 2);
             HIP_TRY(hipMemcpyAsync(h.data(), d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));
@@ -266,9 +293,9 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 continue;
             }
             float ms_i = 0, ms_c = 0, ms_t = 0;
-            HIP_TRY(hipEventElapsedTime(&ms_i, e->ev[0], e->ev[1]));
-            HIP_TRY(hipEventElapsedTime(&ms_c, e->ev[2], e->ev[3]));
-            HIP_TRY(hipEventElapsedTime(&ms_t, e->ev[0], e->ev[3]));
+            HIP_TRY(hipEventElapsedTime(&ms_i, e->lane0.ev[0], e->lane0.ev[1]));
+            HIP_TRY(hipEventElapsedTime(&ms_c, e->lane0.ev[2], e->lane0.ev[3]));
+            HIP_TRY(hipEventElapsedTime(&ms_t, e->lane0.ev[0], e->lane0.ev[3]));
             out->timing.integral_ms += ms_i;
             out->timing.cascade_ms += ms_c;
             out->timing.total_ms += ms_t;

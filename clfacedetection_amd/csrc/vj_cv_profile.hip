@@ -1,15 +1,21 @@
-// gfx950 kernel of the OpenCV arithmetic profile: cvHaarDetectObjects' scale-cascade path as the
-// reference keeps it in tempcv.cpp (a private copy of OpenCV 2.4.2 haar.cpp) —
-//   cvRunHaarClassifierCascadeSum   tempcv.cpp:795-972   f64 variance, f64 node and stage sums, border rule
-//   icvEvalHidHaarClassifier        tempcv.cpp:771-792   sum < t ? left : right
+// gfx950 kernels of the OpenCV arithmetic profile: cvHaarDetectObjects' scale-cascade path as the
+// reference keeps it in tempcv.cpp (a private copy of OpenCV 2.4.2 haar.cpp; CV_HAAR_USE_SSE is commented
+// out at :28-36, so the scalar branches are the specification) —
+//   cvRunHaarClassifierCascadeSum   tempcv.cpp:795-972   f64 variance and stage sums, border rule, three paths:
+//       stage tree (:834-861), stump cascade (:863-945, per-stage two_rects), general trees (:947-964)
+//   icvEvalHidHaarClassifier        tempcv.cpp:771-792   sum < t ? left : right, int * float products
 //   HaarDetectObjects_ScaleCascade_Invoker  :1116-1185    x = cvRound(ix * ystep), ixstep = result != 0 ? 1 : 2
+//   tilted rectangles               tempcv.cpp:743-750   four corners in the tilted integral image
 // Second arithmetic profile of the library; the clod profile (vj_kernels.hip) is the
 // contract of the headline path.  MUST be compiled with -ffp-contract=off.
 //
-// One wave walks one window row.  The sequential "skip the next window after a stage-0 reject" rule is a
+// One wave walks one window row.  The sequential "skip the next window after a reject" rule is a
 // recurrence over the row, e[i] = !(e[i-1] && f[i-1]); because a window that follows a non-reject is always
-// visited, e[i] only depends on the PARITY of the run of stage-0 rejects that ends at i-1 (f computed for
-// every grid position), which a wave gets from one __ballot per 64 positions plus one carry bit.
+// visited, e[i] only depends on the PARITY of the run of rejects that ends at i-1 (f computed for
+// every grid position), which a wave gets from one __ballot per 64 positions plus one carry bit.  For linear
+// cascades only a stage-0 reject skips (the later stages return -i != 0), so f is the stage-0 verdict and the
+// later stages run on the visited survivors; a stage tree returns 0 on ANY reject, so there f is the verdict of
+// the whole tree, evaluated for every grid position.
 #include <hip/hip_runtime.h>
 #include "vj_device.hpp"
 #include "vj_devutil.hpp"
@@ -24,36 +30,50 @@ struct CvQEntry {
 
 __device__ __forceinline__ int cv_round(double v) { return __double2int_rn(v); }   // cvRound: half to even
 
-// One node: sum of the weighted rectangles in f64 (tempcv.cpp:868-888): (double)int * (double)float, added in order.
-__device__ __forceinline__ double cv_node_sum(rsrc_t img, const NodeRecDev& r, uint32_t off) {
-    const uint32_t dw0 = (uint32_t)(int32_t)(int16_t)(r[6] & 0xffffu), dw1 = (uint32_t)((int32_t)r[6] >> 16),
-                   dw2 = (uint32_t)(int32_t)(int16_t)(r[7] & 0xffffu);
-    const int32_t r0 = (int32_t)(ld_u32(img, off, r[0]) - ld_u32(img, off, r[0] + dw0) - ld_u32(img, off, r[0] + r[3]) +
-                                 ld_u32(img, off, r[0] + r[3] + dw0));
-    const int32_t r1 = (int32_t)(ld_u32(img, off, r[1]) - ld_u32(img, off, r[1] + dw1) - ld_u32(img, off, r[1] + r[4]) +
-                                 ld_u32(img, off, r[1] + r[4] + dw1));
-    double s = (double)r0 * (double)__uint_as_float(r[8]);
-    s += (double)r1 * (double)__uint_as_float(r[9]);
-    if (__uint_as_float(r[10]) != 0.0f) {   // uniform
-        const int32_t r2 = (int32_t)(ld_u32(img, off, r[2]) - ld_u32(img, off, r[2] + dw2) - ld_u32(img, off, r[2] + r[5]) +
-                                     ld_u32(img, off, r[2] + r[5] + dw2));
-        s += (double)r2 * (double)__uint_as_float(r[10]);
+// calc_sum(rect, offset) = p0 - p1 - p2 + p3 in int (sumtype; tempcv.cpp:118-121): corner q of rectangle k sits
+// at lt + {0, da, db, da + db}.  Upright: da = width, db = height * stride; tilted (:743-750): da = height *
+// (stride - 1), db = width * (stride + 1).
+__device__ __forceinline__ int32_t cv_calc_sum(rsrc_t img, uint32_t off, uint32_t lt, uint32_t da, uint32_t db) {
+    return (int32_t)(ld_u32(img, off, lt) - ld_u32(img, off, lt + da) - ld_u32(img, off, lt + db) + ld_u32(img, off, lt + da + db));
+}
+
+// One node's weighted rectangle sum.  F64 = a stump stage flagged two_rects (tempcv.cpp:872-888):
+// `double rect0 = calc_sum(..); rect0 *= weight; ... sum = rect1 + rect0` — f64 products.  Otherwise (:783-788,
+// :907-911) `calc_sum(..) * weight` is int * float: the int is converted to binary32 (rounding above 2^24), the
+// product is a binary32 product, and only then is it widened to double and accumulated.
+template <bool F64>
+__device__ __forceinline__ double cv_node_sum(rsrc_t sum_img, rsrc_t tilt_img, const NodeRecDev& r, uint32_t off) {
+    const rsrc_t img = (r[15] & CV_NODE_TILTED) ? tilt_img : sum_img;   // uniform
+    const int32_t r0 = cv_calc_sum(img, off, r[0], r[3], r[6]);
+    const int32_t r1 = cv_calc_sum(img, off, r[1], r[4], r[7]);
+    const float w0 = __uint_as_float(r[9]), w1 = __uint_as_float(r[10]), w2 = __uint_as_float(r[11]);
+    if (F64) {
+        const double rect0 = (double)r0 * (double)w0;
+        const double rect1 = (double)r1 * (double)w1;
+        return rect1 + rect0;   // two_rects: there is no third rectangle
+    }
+    double s = (double)((float)r0 * w0);
+    s += (double)((float)r1 * w1);
+    if (w2 != 0.0f) {   // uniform (node->feature.rect[2].p0 != 0)
+        const int32_t r2 = cv_calc_sum(img, off, r[2], r[5], r[8]);
+        s += (double)((float)r2 * w2);
     }
     return s;
 }
 
 // One stage on one window: stumps through the scalar cache; multi-node trees visit their records in index
 // order under the lanes whose walk sits on them (a child always follows its parent), as stage_sum_trees does.
-template <bool TREES>
-__device__ __forceinline__ double cv_stage_sum(rsrc_t img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off, double vnf) {
+template <bool TREES, bool F64>
+__device__ __forceinline__ double cv_stage_sum(rsrc_t img, rsrc_t timg, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
+                                               double vnf) {
     double stage_sum = 0.0;
     if (!TREES) {
         NodeRecDev r = tab[0];
         for (uint32_t j = 0; j < n_nodes; ++j) {
             const NodeRecDev rn = tab[j + 1 < n_nodes ? j + 1 : j];
-            const double t = (double)__uint_as_float(r[11]) * vnf;
-            const double s = cv_node_sum(img, r, off);
-            stage_sum += (double)(s < t ? __uint_as_float(r[12]) : __uint_as_float(r[13]));
+            const double t = (double)__uint_as_float(r[12]) * vnf;
+            const double s = cv_node_sum<F64>(img, timg, r, off);
+            stage_sum += (double)(s < t ? __uint_as_float(r[13]) : __uint_as_float(r[14]));   // alpha[sum >= t]
             r = rn;
         }
         return stage_sum;
@@ -63,11 +83,11 @@ __device__ __forceinline__ double cv_stage_sum(rsrc_t img, kptr<NodeRecDev> tab,
     bool done = false;
     for (uint32_t j = 0; j < n_nodes; ++j) {
         const NodeRecDev r = tab[j];
-        const uint32_t flags = r[7] >> 16;
+        const uint32_t flags = r[15];
         if (!done && cur == k) {
-            const double t = (double)__uint_as_float(r[11]) * vnf;
-            const bool go_left = cv_node_sum(img, r, off) < t;
-            const uint32_t nxt = go_left ? r[12] : r[13];
+            const double t = (double)__uint_as_float(r[12]) * vnf;
+            const bool go_left = cv_node_sum<false>(img, timg, r, off) < t;
+            const uint32_t nxt = go_left ? r[13] : r[14];
             if (go_left ? (flags & 1u) != 0u : (flags & 2u) != 0u) {
                 cur = nxt;
             } else {
@@ -86,14 +106,23 @@ __device__ __forceinline__ double cv_stage_sum(rsrc_t img, kptr<NodeRecDev> tab,
     return stage_sum;
 }
 
+// Stage sum with the stage's arithmetic mode (StageDev::cv_f64, host-computed: two_rects && stump cascade && no
+// stage tree).
+template <bool TREES>
+__device__ __forceinline__ double cv_stage_sum_mode(rsrc_t img, rsrc_t timg, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
+                                                    double vnf, uint32_t f64) {
+    if (!TREES && f64 != 0u) return cv_stage_sum<false, true>(img, timg, tab, n_nodes, off, vnf);
+    return cv_stage_sum<TREES, false>(img, timg, tab, n_nodes, off, vnf);
+}
+
 template <bool TREES, bool COUNT>
-__device__ __forceinline__ void cv_flush(const CvArgs& a, rsrc_t img, kptr<NodeRecDev> table, CvQEntry* q, uint32_t& n,
+__device__ __forceinline__ void cv_flush(const CvArgs& a, rsrc_t img, rsrc_t timg, kptr<NodeRecDev> table, CvQEntry* q, uint32_t& n,
                                          uint32_t slot, uint32_t frame, uint32_t lane) {
     kptr<StageDev> stages = as_k(a.stages);
     for (uint32_t s = 1; s < a.n_stages && n != 0u; ++s) {
         if (COUNT && lane == 0) atomicAdd(a.stage_entered + s, (unsigned long long)n);
         kptr<NodeRecDev> tab = table + stages[s].first_node;
-        const uint32_t n_nodes = stages[s].n_nodes;
+        const uint32_t n_nodes = stages[s].n_nodes, f64 = stages[s].cv_f64;
         const double thr = (double)stages[s].threshold;
         uint32_t m = 0;
         for (uint32_t base = 0; base < n; base += 64u) {
@@ -101,7 +130,7 @@ __device__ __forceinline__ void cv_flush(const CvArgs& a, rsrc_t img, kptr<NodeR
             const bool act = i < n;
             const CvQEntry e = q[act ? i : 0u];
             bool pass = false;
-            if (act) pass = cv_stage_sum<TREES>(img, tab, n_nodes, e.off, e.vnf) >= thr;
+            if (act) pass = cv_stage_sum_mode<TREES>(img, timg, tab, n_nodes, e.off, e.vnf, f64) >= thr;
             const unsigned long long mask = __ballot(pass);
             __builtin_amdgcn_wave_barrier();
             if (pass) q[m + mbcnt(mask)] = e;
@@ -120,7 +149,22 @@ __device__ __forceinline__ void cv_flush(const CvArgs& a, rsrc_t img, kptr<NodeR
     n = 0;
 }
 
-template <bool TREES, bool COUNT>
+// Which of 64 consecutive grid positions the sequential walk visits, given the reject bits F of all of them and
+// the parity `carry` of the reject run that ends just before the first one; updates carry for the next 64.
+__device__ __forceinline__ bool cv_visited(unsigned long long F, uint32_t lane, uint32_t n_valid, uint32_t& carry) {
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long zeros = ~F & below;
+    uint32_t parity;
+    if (zeros == 0ull) parity = (lane & 1u) ^ carry;
+    else parity = (lane - 1u - (63u - (uint32_t)__clzll((long long)zeros))) & 1u;
+    const unsigned long long vmask = n_valid == 64u ? ~0ull : (1ull << n_valid) - 1ull;
+    const unsigned long long zall = ~F & vmask;
+    if (zall == 0ull) carry ^= n_valid & 1u;
+    else carry = (n_valid - 1u - (63u - (uint32_t)__clzll((long long)zall))) & 1u;
+    return lane < n_valid && parity == 0u;
+}
+
+template <bool TREES, bool COUNT, bool STAGE_TREE>
 __global__ __launch_bounds__(CV_WAVES_PER_BLOCK * 64) void cv_profile_pass(CvArgs a) {
     __shared__ CvQEntry lds_q[CV_WAVES_PER_BLOCK * CV_QCAP];
     const uint32_t lane = lane_id();
@@ -132,8 +176,8 @@ __global__ __launch_bounds__(CV_WAVES_PER_BLOCK * 64) void cv_profile_pass(CvArg
     kptr<StageDev> stages = as_k(a.stages);
     const uint32_t frame_bytes4 = a.frame_elems * 4u;
     const rsrc_t img = make_rsrc(a.sum, a.n_frames * frame_bytes4);
+    const rsrc_t timg = make_rsrc(a.tilted != nullptr ? a.tilted : a.sum, a.n_frames * frame_bytes4);
     const uint32_t total = a.n_rows * a.n_frames;
-    const unsigned long long below = (1ull << lane) - 1ull;
 
     for (uint32_t u = rank; u < total; u += a.total_waves) {
         const uint32_t frame = u / a.n_rows;
@@ -148,7 +192,7 @@ __global__ __launch_bounds__(CV_WAVES_PER_BLOCK * 64) void cv_profile_pass(CvArg
         const uint32_t y = (uint32_t)cv_round((double)iy * ystep);
         const bool row_border = y + win_h >= a.sum_h;          // pt.y + height >= sum.height -> -1 (tempcv.cpp:817-820)
         const double thr0 = (double)stages[0].threshold;
-        uint32_t carry = 0;   // parity of the run of stage-0 rejects that ends at the last position seen
+        uint32_t carry = 0;   // parity of the run of rejects that ends at the last position seen
         uint32_t n_q = 0;
         for (uint32_t ix0 = 0; ix0 < end_x; ix0 += 64u) {
             const uint32_t ix = ix0 + lane;
@@ -157,9 +201,9 @@ __global__ __launch_bounds__(CV_WAVES_PER_BLOCK * 64) void cv_profile_pass(CvArg
             const bool border = row_border || x + win_w >= a.stride;
             const uint32_t po = y * a.stride + x;
             const uint32_t off = frame_bytes + po * 4u;
-            bool fail0 = false;
             double vnf = 1.0;
-            if (valid && !border) {
+            const bool eval = valid && !border;
+            if (eval) {
                 const int32_t isum = (int32_t)(ld_u32(img, off, q0 * 4u) - ld_u32(img, off, q1 * 4u) - ld_u32(img, off, q2 * 4u) +
                                                ld_u32(img, off, q3 * 4u));
                 const uint64_t qq = ld_u64(sq_f, po * 8u, q0 * 8u) - ld_u64(sq_f, po * 8u, q1 * 8u) - ld_u64(sq_f, po * 8u, q2 * 8u) +
@@ -168,15 +212,50 @@ __global__ __launch_bounds__(CV_WAVES_PER_BLOCK * 64) void cv_profile_pass(CvArg
                 vnf = (double)qq;
                 vnf = vnf * inv_area - mean * mean;
                 vnf = vnf >= 0.0 ? sqrt(vnf) : 1.0;
-                fail0 = !(cv_stage_sum<TREES>(img, table + stages[0].first_node, stages[0].n_nodes, off, vnf) >= thr0);
             }
+            const uint32_t n_valid = min(64u, end_x - ix0);
+            if (STAGE_TREE) {
+                // the whole stage tree for every grid position (tempcv.cpp:834-861): every queued lane carries the
+                // stage it visits next; stages are swept once in a topological order of the pass / fail graph
+                int32_t ptr = eval ? (int32_t)stages[0].order : -3;   // -1 accepted, -2 rejected, -3 not evaluated
+                unsigned long long entered = 0ull;
+                for (uint32_t oi = 0; oi < a.n_order; ++oi) {
+                    const uint32_t s = stages[oi].order;
+                    const bool here = ptr == (int32_t)s;
+                    if (__ballot(here) == 0ull) continue;
+                    if (here) {
+                        const bool pass = cv_stage_sum<TREES, false>(img, timg, table + stages[s].first_node, stages[s].n_nodes, off, vnf) >=
+                                          (double)stages[s].threshold;
+                        ptr = pass ? stages[s].on_pass : stages[s].on_fail;
+                        entered |= 1ull << s;
+                    }
+                }
+                const unsigned long long F = __ballot(ptr == -2);
+                const bool visited = cv_visited(F, lane, n_valid, carry);
+                if (COUNT) {
+                    const unsigned long long vm = __ballot(visited);
+                    if (lane == 0) atomicAdd(a.stage_entered + VJ_MAX_STAGES_DEV, (unsigned long long)__popcll(vm));
+                    for (uint32_t s = 0; s < a.n_stages; ++s) {
+                        const unsigned long long em = __ballot(visited && ((entered >> s) & 1ull) != 0ull);
+                        if (lane == 0 && em != 0ull) atomicAdd(a.stage_entered + s, (unsigned long long)__popcll(em));
+                    }
+                }
+                const unsigned long long am = __ballot(visited && ptr == -1);
+                if (am != 0ull) {
+                    uint32_t g = 0;
+                    if (lane == 0) g = atomicAdd(a.det_count, (uint32_t)__popcll(am));
+                    g = __builtin_amdgcn_readfirstlane(g);
+                    const uint32_t pos = g + mbcnt(am);
+                    if (visited && ptr == -1 && pos < a.det_cap) a.det[pos] = CvDet{x, y, slot, frame};
+                }
+                continue;
+            }
+            bool fail0 = false;
+            if (eval)
+                fail0 = !(cv_stage_sum_mode<TREES>(img, timg, table + stages[0].first_node, stages[0].n_nodes, off, vnf, stages[0].cv_f64) >= thr0);
             // which positions does the sequential walk visit?  parity of the reject run below each lane
             const unsigned long long F = __ballot(fail0);
-            const unsigned long long zeros = ~F & below;
-            uint32_t parity;
-            if (zeros == 0ull) parity = (lane & 1u) ^ carry;
-            else parity = (lane - 1u - (63u - (uint32_t)__clzll((long long)zeros))) & 1u;
-            const bool visited = valid && parity == 0u;
+            const bool visited = cv_visited(F, lane, n_valid, carry);
             const bool pass0 = visited && !border && !fail0;
             if (COUNT) {
                 const unsigned long long vm = __ballot(visited), em = __ballot(visited && !border);
@@ -188,30 +267,101 @@ __global__ __launch_bounds__(CV_WAVES_PER_BLOCK * 64) void cv_profile_pass(CvArg
             const unsigned long long pm = __ballot(pass0);
             if (pass0) q[n_q + mbcnt(pm)] = CvQEntry{off, x | (y << 16), vnf};
             n_q += (uint32_t)__popcll(pm);
-            // carry for the next 64 positions
-            const uint32_t n_valid = min(64u, end_x - ix0);
-            const unsigned long long vmask = n_valid == 64u ? ~0ull : (1ull << n_valid) - 1ull;
-            const unsigned long long zall = ~F & vmask;
-            if (zall == 0ull) carry ^= n_valid & 1u;
-            else carry = (n_valid - 1u - (63u - (uint32_t)__clzll((long long)zall))) & 1u;
             __builtin_amdgcn_wave_barrier();
-            if (n_q > (uint32_t)CV_QCAP - 64u) cv_flush<TREES, COUNT>(a, img, table, q, n_q, slot, frame, lane);
+            if (n_q > (uint32_t)CV_QCAP - 64u) cv_flush<TREES, COUNT>(a, img, timg, table, q, n_q, slot, frame, lane);
         }
-        if (n_q != 0u) cv_flush<TREES, COUNT>(a, img, table, q, n_q, slot, frame, lane);
+        if (!STAGE_TREE && n_q != 0u) cv_flush<TREES, COUNT>(a, img, timg, table, q, n_q, slot, frame, lane);
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-int launch_cv_profile_pass(const CvArgs& a, bool trees, bool count, int n_blocks, void* stream_) {
+template <bool TREES, bool STAGE_TREE>
+static void cv_launch(const CvArgs& a, bool count, dim3 g, dim3 b, hipStream_t stream) {
+    if (count) hipLaunchKernelGGL((cv_profile_pass<TREES, true, STAGE_TREE>), g, b, 0, stream, a);
+    else       hipLaunchKernelGGL((cv_profile_pass<TREES, false, STAGE_TREE>), g, b, 0, stream, a);
+}
+
+int launch_cv_profile_pass(const CvArgs& a, bool trees, bool count, bool stage_tree, int n_blocks, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     dim3 g(n_blocks), b(CV_WAVES_PER_BLOCK * 64);
-    if (trees) {
-        if (count) hipLaunchKernelGGL((cv_profile_pass<true, true>), g, b, 0, stream, a);
-        else       hipLaunchKernelGGL((cv_profile_pass<true, false>), g, b, 0, stream, a);
+    if (stage_tree) {
+        if (trees) cv_launch<true, true>(a, count, g, b, stream);
+        else       cv_launch<false, true>(a, count, g, b, stream);
     } else {
-        if (count) hipLaunchKernelGGL((cv_profile_pass<false, true>), g, b, 0, stream, a);
-        else       hipLaunchKernelGGL((cv_profile_pass<false, false>), g, b, 0, stream, a);
+        if (trees) cv_launch<true, false>(a, count, g, b, stream);
+        else       cv_launch<false, false>(a, count, g, b, stream);
     }
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------ tilted integral
+// cvIntegral's tilted sum (OpenCV 2.4.2 imgproc; tilted(X, Y) = sum of gray(x, y) over y < Y, |x - X + 1| <= Y - y - 1)
+// by its row recurrence
+//   T[Y][X] = T[Y-1][X-1] + T[Y-1][X+1] - T[Y-2][X] + I(X-1, Y-1) + I(X-1, Y-2),
+//   T[Y][-1] = T[Y-1][0],  T[Y][W+1] = T[Y-1][W]   (a triangle whose apex lies outside the image),
+// exact in 32 bits modulo 2^32 like CV_32S.  Rows depend on the two rows above, columns do not depend on each other:
+// one workgroup per frame walks the rows with the last three rows in LDS, 1024 columns at a time.  Only cascades with
+// tilted features in the OpenCV profile ask for it; it is not on the headline path.
+__device__ __forceinline__ uint32_t gray_at(const uint8_t* row, uint32_t x, uint32_t ch) {
+    if (ch <= 1u) return row[x];
+    const uint8_t* p = row + (size_t)x * ch;
+    return (p[0] * 1868u + p[1] * 9617u + p[2] * 4899u + 8192u) >> 14;   // OpenCV's 8-bit BGR2GRAY, as the integral kernels
+}
+
+__global__ __launch_bounds__(1024) void tilted_rows(TiltedArgs a) {
+    extern __shared__ uint32_t lds_rows[];   // 3 rows of (W + 1)
+    const uint32_t frame = blockIdx.x;
+    const uint32_t ow = a.width + 1u;
+    const uint8_t* img = a.gray + (size_t)frame * a.gray_frame_bytes;
+    uint32_t* out = a.tilted + (size_t)frame * a.frame_elems;
+    for (uint32_t x = threadIdx.x; x < ow; x += 1024u) {
+        lds_rows[x] = 0u;   // row 0
+        out[x] = 0u;
+    }
+    __syncthreads();
+    for (uint32_t Y = 1; Y <= a.height; ++Y) {
+        const uint32_t* t1 = lds_rows + ((Y - 1u) % 3u) * ow;
+        const uint32_t* t2 = lds_rows + ((Y + 1u) % 3u) * ow;   // (Y - 2) mod 3
+        uint32_t* cur = lds_rows + (Y % 3u) * ow;
+        const uint8_t* i1 = img + (size_t)(Y - 1u) * a.gray_stride;
+        const uint8_t* i2 = img + (size_t)(Y >= 2u ? Y - 2u : 0u) * a.gray_stride;
+        const bool has2 = Y >= 2u;
+        for (uint32_t X = threadIdx.x; X < ow; X += 1024u) {
+            const uint32_t left = X >= 1u ? t1[X - 1u] : (has2 ? t2[0] : 0u);
+            const uint32_t right = X + 1u < ow ? t1[X + 1u] : (has2 ? t2[a.width] : 0u);
+            const uint32_t up2 = has2 ? t2[X] : 0u;
+            uint32_t px = 0u;
+            if (X >= 1u) px = gray_at(i1, X - 1u, a.channels) + (has2 ? gray_at(i2, X - 1u, a.channels) : 0u);
+            const uint32_t v = left + right - up2 + px;
+            cur[X] = v;
+            out[(size_t)Y * ow + X] = v;
+        }
+        __syncthreads();
+    }
+}
+
+int launch_tilted_integral(const TiltedArgs& a, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const size_t lds = (size_t)3 * (a.width + 1u) * sizeof(uint32_t);
+    if (lds > 160u * 1024u) return (int)hipErrorInvalidValue;
+    if (lds > 64u * 1024u) {
+        const hipError_t e = hipFuncSetAttribute((const void*)tilted_rows, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    hipLaunchKernelGGL(tilted_rows, dim3(a.n_frames), dim3(1024), lds, stream, a);
+    return (int)hipGetLastError();
+}
+
+// ------------------------------------------------------------------------ gray image
+// clifGrayscale (clif.h:55-58 -> cvCvtColor BGR2GRAY): the gray image the integral kernels see, as its own output.
+__global__ __launch_bounds__(256) void gray_rows(TiltedArgs a, uint8_t* dst, uint32_t dst_stride) {
+    const uint32_t x = blockIdx.x * 256u + threadIdx.x, y = blockIdx.y;
+    if (x >= a.width) return;
+    dst[(size_t)y * dst_stride + x] = (uint8_t)gray_at(a.gray + (size_t)y * a.gray_stride, x, a.channels);
+}
+
+int launch_grayscale(const TiltedArgs& a, uint8_t* dst, uint32_t dst_stride, void* stream_) {
+    hipLaunchKernelGGL(gray_rows, dim3((a.width + 255u) / 256u, a.height), dim3(256), 0, (hipStream_t)stream_, a, dst, dst_stride);
     return (int)hipGetLastError();
 }
 

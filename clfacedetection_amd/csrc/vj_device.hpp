@@ -37,7 +37,11 @@ struct ScaleDev {
                            // wave's gathers of one corner touch CONSECUTIVE dwords: no bank conflicts)
     int32_t  te_dw;        // equ_rect left->right distance in tile elements (signed when de-interleaved)
     uint32_t tile_x4;      // rows are staged 16 bytes per lane (pitch is a multiple of 4 dwords)
-    uint32_t pad[6];
+    uint32_t skip_base;    // P2 skip modes: first word of this scale in a frame's visited-window bitmap
+    uint32_t skip_wpr;     // ... words per window row (VJ_FLAG_SKIP_ROW); 0: one flattened bit list (VJ_FLAG_SKIP_LIST)
+    float    scale_f;      // s_k itself, and the scaled window: what a region of interest needs to lay out its own grid
+    uint32_t win_w, win_h; // ... (setupScale, clod.cpp:371-415, evaluated on the device per region: roi_plan_units)
+    uint32_t pad[1];
 };
 static_assert(sizeof(ScaleDev) == 128, "ScaleDev is 128 bytes");
 
@@ -53,7 +57,8 @@ struct StageDev {
     uint32_t sp_first;     // stump-parallel finish: index of the stage's first block in CascadeArgs::sp_blocks
     float    sp_delta;     // ... |tree-order stage sum - sequential stage sum| <= sp_delta for ANY window (see
                            //     tile_stump_parallel): 4 * n * 2^-24 * sum_k max(|left_k|, |right_k|), rounded up
-    uint32_t pad[3];
+    uint32_t cv_f64;       // OpenCV profile: this stage multiplies in f64 (two_rects stump stage, tempcv.cpp:872-888)
+    uint32_t pad[2];
 };
 static_assert(sizeof(StageDev) == 48, "StageDev is 48 bytes");
 
@@ -78,6 +83,23 @@ struct QEntry {
 struct DetEntry {
     uint32_t off;
     uint32_t scale;        // index into ScaleDev[]
+};
+
+// A region of interest on the device (vj_roi's layout: frame, x, y, w, h) and one unit of work inside it.
+struct RoiDev {
+    int32_t frame, x, y, w, h;
+};
+struct RoiUnit {
+    uint32_t roi;          // index into the region list
+    uint32_t slot;         // scale (index into ScaleDev[])
+    uint32_t first;        // first window of the unit, row-major in the region's own grid of this scale
+    uint32_t count;        // <= UNIT_WINDOWS
+    uint32_t nx, ny;       // the region's grid of this scale
+};
+struct RoiDet {
+    uint32_t off;          // window origin, byte offset in the batch sum image
+    uint32_t slot;
+    uint32_t roi;
 };
 
 // One block of <= 64 consecutive nodes of a stage (stump-parallel finish of the tile kernel).
@@ -162,6 +184,16 @@ struct CascadeArgs {
     uint32_t  det_cap;
     uint32_t  signed_mean;      // VJ_FLAG_SIGNED_MEAN
     unsigned long long* stage_entered;  // [VJ_MAX_STAGES] when counting, else null
+    // P2 skip modes (VJ_FLAG_SKIP_LIST / VJ_FLAG_SKIP_ROW; clod.cpp:729-732, :1430): a bitmap of the grid windows the
+    // reference's sequential CPU loops visit, built by skip_fail_bits + skip_resolve before the cascade passes;
+    // null = every grid window (the OpenCL kernel's contract)
+    unsigned long long* skip_bits;      // [n_frames][skip_frame_words]
+    uint32_t  skip_frame_words;
+    uint32_t  round_away;               // window positions round(index * step) half away from zero (clod.cpp:1416) instead of lrint (:514)
+    const UnitDev* skip_units;          // one per bitmap word of a frame: {scale, first window (flattened index, or ix0 | iy << 16), valid bits, word}
+    uint32_t  n_skip_units;
+    const UnitDev* skip_segs;           // one per recurrence domain (a window row, or a scale's whole list): {scale, first word, words, -}
+    uint32_t  n_skip_segs;
 };
 
 struct IntegralArgs {
@@ -188,6 +220,36 @@ int launch_cascade_pass(const CascadeArgs& a, bool from_grid, bool trees, bool l
                         int n_blocks, void* stream);
 int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, bool staged, int n_blocks, void* stream);
 
+// Regions of interest on the device (vj_detect_chain).
+struct RoiArgs {
+    // dets_to_rois: raw detections of a first cascade -> regions
+    const DetEntry* det_in;
+    const uint32_t* det_in_count;
+    uint32_t det_in_cap;
+    const ScaleDev* scales_in;   // the first cascade's scales (win_w / win_h)
+    uint32_t frame_bytes;        // frame_elems * 4
+    uint32_t stride;             // W + 1
+    RoiDev* rois;                // region list (written by dets_to_rois, or supplied by the caller)
+    uint32_t* n_rois;            // on the device
+    uint32_t max_rois;
+    // roi_plan_units: every region lays out the second cascade's grid inside itself
+    uint32_t n_frames;
+    int32_t  frame_w, frame_h;
+    int32_t  win_w0, win_h0;     // the second cascade's base window
+    int32_t  min_w, min_h, max_w, max_h;
+    RoiUnit* units;
+    uint32_t* n_units;
+    uint32_t max_units;
+    uint32_t* ticket;            // unit ticket counter of cascade_roi_pass
+    // cascade_roi_pass
+    RoiDet* det;
+    uint32_t* det_count;
+    uint32_t det_cap;
+};
+int launch_roi_chain(const RoiArgs& r, const CascadeArgs& a, bool from_dets, bool trees, bool count, int n_blocks, void* stream);
+int launch_skip_bitmap(const CascadeArgs& a, bool trees, int n_blocks, void* stream);   // fail bits, then the visited bitmap
+int prepare_tile_kernels();   // per device: raise the dynamic-LDS cap of the tile kernel's instantiations
+
 }  // namespace vj
 
 // ------------------------------------------------------------ OpenCV arithmetic profile (vj_cv.cpp)
@@ -211,12 +273,27 @@ struct CvDet {
     uint32_t x, y, slot, frame;
 };
 
+// Node record of the OpenCV profile (64 bytes, fetched through the scalar cache like NodeRec): corner q of
+// rectangle k sits at lt[k] + {0, da[k], db[k], da[k] + db[k]} bytes from the window origin — upright rectangles
+// da = width, db = height * stride; tilted ones (tempcv.cpp:743-750) da = height * (stride - 1), db = width *
+// (stride + 1), in the tilted integral image.
+struct alignas(16) CvNodeRec {
+    uint32_t lt[3], da[3], db[3];
+    float    w[3];         // w[2] == 0: two rectangles
+    float    thr;
+    uint32_t left, right;  // f32 leaf value bits, or child node index (flags)
+    uint32_t flags;        // NODE_LEFT_IS_NODE | NODE_RIGHT_IS_NODE | NODE_TREE_LAST | CV_NODE_TILTED
+};
+static_assert(sizeof(CvNodeRec) == 64, "CvNodeRec must be 64 bytes");
+constexpr uint32_t CV_NODE_TILTED = 8u;
+
 constexpr int CV_WAVES_PER_BLOCK = 4;
 constexpr int VJ_MAX_STAGES_DEV = 64;  // == VJ_MAX_STAGES
 constexpr int CV_QCAP = 320;           // survivors of stage 0 a wave collects before it sweeps the later stages
 
 struct CvArgs {
     const uint32_t* sum;
+    const uint32_t* tilted;      // tilted integral images, same geometry as sum (null: no tilted features)
     const uint64_t* sqsum;
     const uint32_t* table;       // NodeRec[] (offsets in bytes, f32 weights per tempcv.cpp:700-768)
     const CvScaleDev* scales;
@@ -225,6 +302,7 @@ struct CvArgs {
     uint32_t n_rows;             // per frame
     uint32_t n_frames;
     uint32_t n_stages;
+    uint32_t n_order;            // stage trees: stages reachable from stage 0, swept in StageDev::order
     uint32_t frame_elems;
     uint32_t stride;             // W + 1
     uint32_t sum_h;              // H + 1
@@ -235,6 +313,19 @@ struct CvArgs {
     unsigned long long* stage_entered;   // [VJ_MAX_STAGES] + [VJ_MAX_STAGES] = windows visited (border ones included)
 };
 
-int launch_cv_profile_pass(const CvArgs& a, bool trees, bool count, int n_blocks, void* stream);
+int launch_cv_profile_pass(const CvArgs& a, bool trees, bool count, bool stage_tree, int n_blocks, void* stream);
+
+struct TiltedArgs {
+    const uint8_t* gray;        // batch of frames
+    uint64_t gray_frame_bytes;
+    uint32_t gray_stride;
+    uint32_t channels;
+    uint32_t width, height;
+    uint32_t n_frames;
+    uint32_t frame_elems;
+    uint32_t* tilted;           // [frames][frame_elems], rows of W + 1
+};
+int launch_tilted_integral(const TiltedArgs& a, void* stream);
+int launch_grayscale(const TiltedArgs& a, uint8_t* dst, uint32_t dst_stride, void* stream);
 
 }  // namespace vj

@@ -73,6 +73,8 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         return VJ_ERR_LIMIT;
     }
     pl->prog = build_stage_program(c);
+    const uint32_t skip_mode = p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW);
+    pl->skip_mode = skip_mode;
     for (const auto& t : c.trees)
         if (t.n_nodes != 1) pl->trees = true;
     if (pl->trees) {
@@ -95,39 +97,11 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                              (pl->prog.on_pass[s] == STAGE_ACCEPT && s + 1 == c.stages.size()));
         if (!linear) pl->general = true;
     }
-    // Topological order of the pass/fail graph rooted at stage 0 (depth-first, pass edge
-    // first): the general path sweeps the stages once in this order.
+    // Topological order of the pass/fail graph rooted at stage 0: the general path sweeps the stages once in it.
     std::vector<uint32_t> order;
-    {
-        const int nS = (int)c.stages.size();
-        std::vector<int> state(nS, 0);  // 0 unvisited, 1 on stack, 2 done
-        std::vector<uint32_t> post;
-        bool cyclic = false;
-        std::vector<std::pair<int, int>> stack{{0, 0}};
-        state[0] = 1;
-        while (!stack.empty()) {
-            auto& [s, phase] = stack.back();
-            if (phase < 2) {
-                const int nxt = phase == 0 ? pl->prog.on_pass[s] : pl->prog.on_fail[s];
-                ++phase;
-                if (nxt >= 0) {
-                    if (state[nxt] == 1) cyclic = true;
-                    if (state[nxt] == 0) {
-                        state[nxt] = 1;
-                        stack.push_back({nxt, 0});
-                    }
-                }
-            } else {
-                state[s] = 2;
-                post.push_back((uint32_t)s);
-                stack.pop_back();
-            }
-        }
-        if (cyclic) {
-            set_error("stage links form a cycle");
-            return VJ_ERR_UNSUPPORTED;
-        }
-        order.assign(post.rbegin(), post.rend());  // reverse post-order; unreachable stages are dropped
+    if (!stage_sweep_order(pl->prog, &order)) {
+        set_error("stage links form a cycle");
+        return VJ_ERR_UNSUPPORTED;
     }
     if (pl->general && e->general_prefix) {
         // the linear head of a stage tree (frontalface_alt_tree: stages 0..4 before the two chains split)
@@ -173,12 +147,16 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         sd.area = (float)si.area;
         sd.table_first = (uint32_t)table.size();
         sd.scale_idx = (uint32_t)si.scale_idx;
+        sd.scale_f = si.scale;
+        sd.win_w = (uint32_t)si.win_w;
+        sd.win_h = (uint32_t)si.win_h;
         table.resize(table.size() + n_nodes);
         int rc = build_node_table(c, W, si, table.data() + sd.table_first);
         if (rc) return rc;
         // furthest element any gather of this scale can touch, relative to frame start
-        const uint32_t x_max = (uint32_t)std::lrint((double)((float)(si.nx - 1) * si.step));
-        const uint32_t y_max = (uint32_t)std::lrint((double)((float)(si.ny - 1) * si.step));
+        // (positions are lrint(i * step), or round() half away from zero in VJ_FLAG_SKIP_ROW mode: one more covers both)
+        const uint32_t x_max = (uint32_t)std::lrint((double)((float)(si.nx - 1) * si.step)) + (skip_mode == VJ_FLAG_SKIP_ROW ? 1u : 0u);
+        const uint32_t y_max = (uint32_t)std::lrint((double)((float)(si.ny - 1) * si.step)) + (skip_mode == VJ_FLAG_SKIP_ROW ? 1u : 0u);
         uint32_t reach = sd.e_lt + sd.e_dh + sd.e_dw;
         for (size_t k = 0; k < n_nodes; ++k) {
             const NodeRec& r = table[sd.table_first + k];
@@ -465,7 +443,45 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     pl->n_block_units = (uint32_t)pl->tile_units.size() - pl->block_first;
     pl->block_lds = tile_header_bytes;
 
+    // P2 skip modes: one bitmap word per 64 consecutive windows of a recurrence domain — a window row
+    // (VJ_FLAG_SKIP_ROW, clod.cpp:1430) or a scale's whole row-major list (VJ_FLAG_SKIP_LIST, clod.cpp:729-732)
+    std::vector<UnitDev> skip_units, skip_segs;
+    if (skip_mode) {
+        if (pl->general) {
+            set_error("the skip modes restate the reference's CPU loops, which run linear cascades only");
+            return VJ_ERR_UNSUPPORTED;
+        }
+        uint32_t word = 0;
+        for (uint32_t slot = 0; slot < pl->scales.size(); ++slot) {
+            ScaleDev& sd = pl->scales[slot];
+            sd.skip_base = word;
+            if (skip_mode == VJ_FLAG_SKIP_ROW) {
+                sd.skip_wpr = (sd.nx + 63u) / 64u;
+                for (uint32_t iy = 0; iy < sd.ny; ++iy) {
+                    skip_segs.push_back(UnitDev{slot, word, sd.skip_wpr, 0});
+                    for (uint32_t ix0 = 0; ix0 < sd.nx; ix0 += 64u)
+                        skip_units.push_back(UnitDev{slot, ix0 | (iy << 16), std::min<uint32_t>(64u, sd.nx - ix0), word++});
+                }
+            } else {
+                sd.skip_wpr = 0;
+                const uint32_t n_words = (sd.nwin + 63u) / 64u;
+                skip_segs.push_back(UnitDev{slot, word, n_words, 0});
+                for (uint32_t i0 = 0; i0 < sd.nwin; i0 += 64u)
+                    skip_units.push_back(UnitDev{slot, i0, std::min<uint32_t>(64u, sd.nwin - i0), word++});
+            }
+        }
+        pl->skip_frame_words = word;
+        pl->n_skip_units = (uint32_t)skip_units.size();
+        pl->n_skip_segs = (uint32_t)skip_segs.size();
+    }
+
     int rc;
+    if (!skip_units.empty()) {
+        if ((rc = pl->d_skip_units.ensure(skip_units.size() * sizeof(UnitDev)))) return rc;
+        if ((rc = pl->d_skip_segs.ensure(skip_segs.size() * sizeof(UnitDev)))) return rc;
+        HIP_TRY(hipMemcpy(pl->d_skip_units.p, skip_units.data(), skip_units.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
+        HIP_TRY(hipMemcpy(pl->d_skip_segs.p, skip_segs.data(), skip_segs.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
+    }
     if ((rc = pl->d_table.ensure(std::max<size_t>(table.size(), 1) * sizeof(NodeRec)))) return rc;
     if ((rc = pl->d_scales.ensure(std::max<size_t>(pl->scales.size(), 1) * sizeof(ScaleDev)))) return rc;
     if ((rc = pl->d_stages.ensure(pl->stages.size() * sizeof(StageDev)))) return rc;
@@ -511,29 +527,62 @@ static int layout_queues(Plan* pl, int frames, uint64_t* total_entries) {
 
 static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, Plan** out) {
     vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
-                        p.scale_mask[1]);
+                        p.scale_mask[1], p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW));
     auto it = e->plans.find(key);
     if (it != e->plans.end()) {
+        it->second->last_used = ++e->plan_tick;
         *out = it->second.get();
         return VJ_OK;
+    }
+    // bounded cache: release the least recently used plans first (their kernels may still be running)
+    if ((int)e->plans.size() >= std::max(1, e->plan_cache_max)) {
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        if (e->stream2) HIP_TRY(hipStreamSynchronize(e->stream2));
+        while ((int)e->plans.size() >= std::max(1, e->plan_cache_max)) {
+            auto lru = e->plans.begin();
+            for (auto i = e->plans.begin(); i != e->plans.end(); ++i)
+                if (i->second->last_used < lru->second->last_used) lru = i;
+            lru->second->release_device();
+            e->plans.erase(lru);
+        }
     }
     auto pl = std::make_unique<Plan>();
     int rc = build_plan(e, *c, W, H, p, pl.get());
     if (rc) {
-        pl->d_table.release();
-        pl->d_scales.release();
-        pl->d_stages.release();
-        pl->d_units.release();
-        pl->d_tile_units.release();
-        pl->d_sp_blocks.release();
+        pl->release_device();
         return rc;
     }
+    pl->last_used = ++e->plan_tick;
     *out = pl.get();
     e->plans[key] = std::move(pl);
     return VJ_OK;
 }
 
-int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_gray, int channels) {
+int Lane::create() {
+    for (auto& x : ev) HIP_TRY(hipEventCreate(&x));
+    for (auto& x : pass_ev) HIP_TRY(hipEventCreate(&x));
+    for (auto& x : launch_ev) HIP_TRY(hipEventCreate(&x));
+    HIP_TRY(hipEventCreateWithFlags(&upload_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&integral_done, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    h_pinned_bytes = (size_t)1 << 20;   // counters block (~100 KiB) + the first detections
+    HIP_TRY(hipHostMalloc(&h_pinned, h_pinned_bytes, hipHostMallocDefault));
+    return VJ_OK;
+}
+
+void Lane::destroy() {
+    for (DevBuf* b : {&d_gray, &d_counts, &d_det}) b->release();
+    if (h_pinned) (void)hipHostFree(h_pinned);
+    if (h_stage) (void)hipHostFree(h_stage);
+    h_pinned = h_stage = nullptr;
+    for (auto& x : ev) if (x) (void)hipEventDestroy(x);
+    for (auto& x : pass_ev) if (x) (void)hipEventDestroy(x);
+    for (auto& x : launch_ev) if (x) (void)hipEventDestroy(x);
+    for (hipEvent_t* x : {&upload_done, &integral_done, &done}) if (*x) (void)hipEventDestroy(*x);
+}
+
+int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_gray, int channels, Lane* lane) {
+    if (!lane) lane = &e->lane0;
     const size_t fe = frame_elems_for(W, H);
     const uint32_t n_bands = ((uint32_t)H + BAND_ROWS - 1) / BAND_ROWS;
     const uint32_t band_pitch = ((uint32_t)W + 3u) & ~3u;
@@ -545,7 +594,7 @@ int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_gray, in
     (void)grow;
     if (need_gray) {
         const size_t gstride = ((size_t)W * (size_t)channels + 3) & ~(size_t)3;
-        if ((rc = e->d_gray.ensure(gstride * (size_t)H * (size_t)frames))) return rc;
+        if ((rc = lane->d_gray.ensure(gstride * (size_t)H * (size_t)frames))) return rc;
     }
     const size_t band_elems = (size_t)frames * n_bands * band_pitch;
     if ((rc = e->d_band_sum.ensure(band_elems * 4))) return rc;
@@ -600,12 +649,40 @@ int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int s
     return VJ_OK;
 }
 
+// The tilted integral of `frames` frames already on the device, into e->d_tilted (same geometry as d_sum).
+int enqueue_tilted(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int stride, int W, int H, int frames, int channels) {
+    const uint32_t fe = frame_elems_for(W, H);
+    int rc;
+    if ((rc = e->d_tilted.ensure((size_t)fe * 4u * (size_t)frames))) return rc;
+    // rows past H (the slack rows) must read as zero, like d_sum's
+    HIP_TRY(hipMemsetAsync(e->d_tilted.p, 0, (size_t)fe * 4u * (size_t)frames, e->stream));
+    TiltedArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.gray = d_gray;
+    ta.gray_frame_bytes = frame_bytes;
+    ta.gray_stride = (uint32_t)stride;
+    ta.channels = (uint32_t)channels;
+    ta.width = (uint32_t)W;
+    ta.height = (uint32_t)H;
+    ta.n_frames = (uint32_t)frames;
+    ta.frame_elems = fe;
+    ta.tilted = (uint32_t*)e->d_tilted.p;
+    const int hrc = launch_tilted_integral(ta, e->stream);
+    if (hrc) {
+        set_error("tilted integral launch failed (width %d): %s", W, hipGetErrorString((hipError_t)hrc));
+        return hrc == (int)hipErrorInvalidValue ? VJ_ERR_LIMIT : VJ_ERR_HIP;
+    }
+    return VJ_OK;
+}
+
 // Upload host frames (or gather strided device frames) into d_gray with a 4-byte
 // aligned pitch.  Returns the device pointer / pitch the integral kernels should use.
 int image_channels(const vj_image& im) { return im.channels <= 1 ? 1 : im.channels; }
 
 int stage_frames(vj_env* e, const vj_image* frames, int n, int W, int H, const uint8_t** d_ptr, size_t* frame_bytes,
-                 int* stride) {
+                 int* stride, Lane* lane, hipStream_t copy_stream) {
+    if (!lane) lane = &e->lane0;
+    hipStream_t cs = copy_stream ? copy_stream : e->stream;
     const size_t row_bytes = (size_t)W * (size_t)image_channels(frames[0]);
     bool all_dev = true, contiguous = true;
     for (int i = 0; i < n; ++i) {
@@ -622,11 +699,34 @@ int stage_frames(vj_env* e, const vj_image* frames, int n, int W, int H, const u
     }
     const size_t gstride = (row_bytes + 3) & ~(size_t)3;
     for (int i = 0; i < n; ++i) {
-        uint8_t* dst = (uint8_t*)e->d_gray.p + (size_t)i * gstride * (size_t)H;
-        HIP_TRY(hipMemcpy2DAsync(dst, gstride, frames[i].data, (size_t)frames[i].stride, row_bytes, (size_t)H,
-                                 frames[i].on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, e->stream));
+        uint8_t* dst = (uint8_t*)lane->d_gray.p + (size_t)i * gstride * (size_t)H;
+        const uint8_t* src = frames[i].data;
+        size_t src_stride = (size_t)frames[i].stride;
+        if (copy_stream && !frames[i].on_device) {
+            // streams: the copy must be a true DMA to overlap the kernels — page-locked memory (vj_host_alloc) goes as
+            // it is, pageable memory through this lane's pinned staging buffer
+            hipPointerAttribute_t at;
+            const bool pinned = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
+            if (!pinned) {
+                (void)hipGetLastError();
+                const size_t need = gstride * (size_t)H * (size_t)n;
+                if (lane->h_stage_bytes < need) {
+                    if (lane->h_stage) (void)hipHostFree(lane->h_stage);
+                    lane->h_stage = nullptr;
+                    lane->h_stage_bytes = 0;
+                    HIP_TRY(hipHostMalloc(&lane->h_stage, need, hipHostMallocDefault));
+                    lane->h_stage_bytes = need;
+                }
+                uint8_t* st = (uint8_t*)lane->h_stage + (size_t)i * gstride * (size_t)H;
+                for (int y = 0; y < H; ++y) memcpy(st + (size_t)y * gstride, src + (size_t)y * src_stride, row_bytes);
+                src = st;
+                src_stride = gstride;
+            }
+        }
+        HIP_TRY(hipMemcpy2DAsync(dst, gstride, src, src_stride, row_bytes, (size_t)H,
+                                 frames[i].on_device ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, cs));
     }
-    *d_ptr = (const uint8_t*)e->d_gray.p;
+    *d_ptr = (const uint8_t*)lane->d_gray.p;
     *stride = (int)gstride;
     *frame_bytes = gstride * (size_t)H;
     return VJ_OK;
@@ -637,52 +737,68 @@ struct RawDet {
     uint32_t slot, x, y;
 };
 
-// One sub-batch: frames [f0, f0+nf).  Appends decoded detections to `dets`.
-static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, int nf, int W, int H,
-                           const vj_params& p, std::vector<RawDet>* dets, vj_counters* ctr, vj_timing* tm) {
-    int rc;
-    bool need_gray = false;
-    for (int i = 0; i < nf; ++i)
-        if (!frames[f0 + i].on_device) need_gray = true;
-    // strided / scattered device frames are gathered too
-    need_gray = true;
-    const int channels = image_channels(frames[f0]);
-    if ((rc = ensure_image_buffers(e, W, H, nf, need_gray, channels))) return rc;
-    uint64_t q_entries = 0;
-    if ((rc = layout_queues(pl, nf, &q_entries))) return rc;
-    const size_t n_pass = pl->pass_bounds.size() - 1;
-    for (size_t ps = 1; ps < n_pass; ++ps)
-        if ((rc = e->d_q[ps].ensure(std::max<uint64_t>(q_entries, 1) * sizeof(QEntry)))) return rc;
-    // counters block: [MAX_PASSES][MAX_SCALES] queue counts | det_count | pad | one stage_entered[VJ_MAX_STAGES]
-    // (u64) array per kernel launch (array 0 is spare)
-    const size_t counts_bytes =
-        (MAX_PASSES * MAX_SCALES * Q_PARTS + 2) * sizeof(uint32_t) + (size_t)(1 + VJ_MAX_LAUNCHES) * VJ_MAX_STAGES * sizeof(uint64_t);
-    if ((rc = e->d_counts.ensure(counts_bytes))) return rc;
-    if (e->det_cap == 0) {
-        e->det_cap = e->det_cap_init;
-        if ((rc = e->d_det.ensure((size_t)e->det_cap * sizeof(DetEntry)))) return rc;
-    }
-    uint32_t* d_qcount[MAX_PASSES];
-    const size_t q_counts = (size_t)MAX_SCALES * Q_PARTS;   // counters of one queue: [scale][part]
-    for (int ps = 0; ps < MAX_PASSES; ++ps) d_qcount[ps] = (uint32_t*)e->d_counts.p + ps * q_counts;
-    uint32_t* d_det_count = (uint32_t*)e->d_counts.p + MAX_PASSES * q_counts;
-    unsigned long long* d_stage_entered =
-        (unsigned long long*)((uint32_t*)e->d_counts.p + MAX_PASSES * q_counts + 2);
+// Where the counters of one batch live: [MAX_PASSES][MAX_SCALES][Q_PARTS] queue counts | det_count | pad | one
+// stage_entered[VJ_MAX_STAGES] (u64) array per kernel launch (array 0 is spare) | the counters of a region-of-interest
+// pass (vj_detect_chain): regions, units, invalid regions, unit ticket, detections, pad | its stage_entered array.
+struct CountsLayout {
+    static constexpr size_t q_counts = (size_t)MAX_SCALES * Q_PARTS;   // counters of one queue: [scale][part]
+    static constexpr size_t stage_off_u32 = MAX_PASSES * q_counts + 2;
+    static constexpr size_t roi_off_u32 = stage_off_u32 + (size_t)(1 + VJ_MAX_LAUNCHES) * VJ_MAX_STAGES * 2;
+    static constexpr size_t bytes = (roi_off_u32 + 8 + (size_t)VJ_MAX_STAGES * 2) * sizeof(uint32_t);
+};
 
+// Upload (or adopt) the frames of one batch and enqueue its integral images.  `copy_stream` != null: the upload runs
+// on that stream and the integral waits for it (vj_stream); else everything is ordered on the environment's stream.
+static int enqueue_prepare(vj_env* e, Lane* L, Plan* pl, const vj_image* frames, int nf, int W, int H, bool fixed_queue_layout,
+                           hipStream_t copy_stream) {
+    int rc;
+    const int channels = image_channels(frames[0]);
+    if ((rc = ensure_image_buffers(e, W, H, nf, true, channels, L))) return rc;
+    uint64_t q_entries = 0;
+    if (!fixed_queue_layout) {
+        if ((rc = layout_queues(pl, nf, &q_entries))) return rc;
+        const size_t n_pass = pl->pass_bounds.size() - 1;
+        for (size_t ps = 1; ps < n_pass; ++ps)
+            if ((rc = e->d_q[ps].ensure(std::max<uint64_t>(q_entries, 1) * sizeof(QEntry)))) return rc;
+    }
+    if ((rc = L->d_counts.ensure(CountsLayout::bytes))) return rc;
+    if (L->det_cap == 0) {
+        L->det_cap = e->det_cap_init;
+        if ((rc = L->d_det.ensure((size_t)L->det_cap * sizeof(DetEntry)))) return rc;
+    }
     const uint8_t* d_gray;
     size_t gray_frame_bytes;
     int gray_stride;
-    if ((rc = stage_frames(e, frames + f0, nf, W, H, &d_gray, &gray_frame_bytes, &gray_stride))) return rc;
-
-    HIP_TRY(hipEventRecord(e->ev[0], e->stream));
+    if ((rc = stage_frames(e, frames, nf, W, H, &d_gray, &gray_frame_bytes, &gray_stride, L, copy_stream))) return rc;
+    if (copy_stream) {
+        HIP_TRY(hipEventRecord(L->upload_done, copy_stream));
+        HIP_TRY(hipStreamWaitEvent(e->stream, L->upload_done, 0));
+    }
+    HIP_TRY(hipEventRecord(L->ev[0], e->stream));
     if ((rc = enqueue_integral(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf, channels))) return rc;
-    HIP_TRY(hipEventRecord(e->ev[1], e->stream));
+    HIP_TRY(hipEventRecord(L->ev[1], e->stream));
+    HIP_TRY(hipEventRecord(L->integral_done, e->stream));   // the lane's frame buffer may be overwritten from here on
+    L->nf = nf;
+    return VJ_OK;
+}
 
+// Enqueue every cascade launch of the batch whose integral images are (being) computed, then the asynchronous
+// read-back of its counters and first detections.  Nothing here waits for the device.
+static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_params& p) {
+    int rc;
+    const int nf = L->nf;
+    const size_t n_pass = pl->pass_bounds.size() - 1;
+    const size_t counts_bytes = CountsLayout::bytes;
+    constexpr size_t q_counts = CountsLayout::q_counts;
+    uint32_t* d_qcount[MAX_PASSES];
+    for (int ps = 0; ps < MAX_PASSES; ++ps) d_qcount[ps] = (uint32_t*)L->d_counts.p + ps * q_counts;
+    uint32_t* d_det_count = (uint32_t*)L->d_counts.p + MAX_PASSES * q_counts;
+    unsigned long long* d_stage_entered = (unsigned long long*)((uint32_t*)L->d_counts.p + CountsLayout::stage_off_u32);
     const bool count = (p.flags & VJ_FLAG_COUNTERS) != 0;
     const int n_blocks = std::max(1, e->n_cu * e->blocks_per_cu);
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        HIP_TRY(hipMemsetAsync(e->d_counts.p, 0, counts_bytes, e->stream));
-        HIP_TRY(hipEventRecord(e->ev[2], e->stream));
+    {
+        HIP_TRY(hipMemsetAsync(L->d_counts.p, 0, counts_bytes, e->stream));
+        HIP_TRY(hipEventRecord(L->ev[2], e->stream));
         CascadeArgs ca;
         memset(&ca, 0, sizeof(ca));
         ca.sum = (const uint32_t*)e->d_sum.p;
@@ -700,9 +816,9 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.sum_bytes = (uint32_t)((uint64_t)pl->frame_elems * 4u * (uint64_t)nf);
         ca.stride = (uint32_t)W + 1u;
         ca.total_waves = (uint32_t)n_blocks * WAVES_PER_BLOCK;
-        ca.det = (DetEntry*)e->d_det.p;
+        ca.det = (DetEntry*)L->d_det.p;
         ca.det_count = d_det_count;
-        ca.det_cap = e->det_cap;
+        ca.det_cap = L->det_cap;
         ca.signed_mean = (p.flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
         ca.stage_entered = d_stage_entered;
         ca.n_pass = (uint32_t)n_pass;
@@ -714,7 +830,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.tile_end = pl->general ? pl->general_prefix : (uint32_t)e->tile_end;   // stage trees: tiles run the linear prefix only
         ca.tile_min_lanes = (uint32_t)e->tile_min_lanes;
         ca.tile_repack_mask = e->tile_repack_mask;
-        ca.tile_sp_begin = (pl->sp_pad || pl->tree2) ? (uint32_t)e->tile_sp_begin : 0xffffffffu;
+        ca.tile_sp_begin = (!pl->general && (pl->sp_pad || pl->tree2)) ? (uint32_t)e->tile_sp_begin : 0xffffffffu;   // the finishes walk positions linearly: never on a stage tree
         ca.tree2 = pl->tree2 ? 1u : 0u;
         ca.identity_order = pl->general ? 0u : 1u;
         ca.n_seg = e->tile_segments ? pl->tile_n_seg : 0u;
@@ -728,11 +844,29 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         ca.tile_finish = (uint32_t)e->tile_finish;
         ca.tile_ws_min = pl->sp_pad != 0u ? (uint32_t)e->tile_ws_min : 0u;   // no stump-parallel tables: wave-split to the end
         ca.tile_ws_max = (uint32_t)std::min(e->tile_ws_max, (int)TILE_WS_MAX_WINDOWS);
+        ca.round_away = pl->skip_mode == VJ_FLAG_SKIP_ROW ? 1u : 0u;
+        if (pl->skip_mode && pl->n_skip_units) {
+            // the windows the reference's sequential CPU loop visits, as a bitmap: stage-0 verdict of every grid window,
+            // then the parity recurrence; the passes below drop the unvisited windows while they enumerate the grid
+            if ((rc = e->d_skip_bits.ensure((size_t)pl->skip_frame_words * 8u * (size_t)nf))) return rc;
+            ca.skip_bits = (unsigned long long*)e->d_skip_bits.p;
+            ca.skip_frame_words = pl->skip_frame_words;
+            ca.skip_units = (const UnitDev*)pl->d_skip_units.p;
+            ca.n_skip_units = pl->n_skip_units;
+            ca.skip_segs = (const UnitDev*)pl->d_skip_segs.p;
+            ca.n_skip_segs = pl->n_skip_segs;
+            const int hrc = launch_skip_bitmap(ca, pl->trees, std::max(1, e->n_cu * 4), e->stream);
+            if (hrc) {
+                set_error("skip bitmap launch failed: %s", hipGetErrorString((hipError_t)hrc));
+                return VJ_ERR_HIP;
+            }
+        }
         int launches = 0;
-        std::vector<vj_launch> linfo;
+        std::vector<vj_launch>& linfo = L->linfo;
+        linfo.clear();
         // every launch is bracketed by its own pair of events on the stream it runs on
         auto begin_launch = [&](int kind, int cls, uint32_t sb, uint32_t se, uint32_t lds, hipStream_t st) -> int {
-            if (linfo.size() < VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(e->launch_ev[2 * linfo.size()], st));
+            if (linfo.size() < VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(L->launch_ev[2 * linfo.size()], st));
             vj_launch li;
             memset(&li, 0, sizeof(li));
             li.kind = kind;
@@ -754,7 +888,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             return d_stage_entered + std::min<size_t>(linfo.size(), VJ_MAX_LAUNCHES) * VJ_MAX_STAGES;
         };
         auto end_launch = [&](hipStream_t st) -> int {
-            if (linfo.size() <= VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(e->launch_ev[2 * linfo.size() - 1], st));
+            if (linfo.size() <= VJ_MAX_LAUNCHES) HIP_TRY(hipEventRecord(L->launch_ev[2 * linfo.size() - 1], st));
             return VJ_OK;
         };
         auto pass_is_last = [&](size_t ps) { return pl->seg_last.empty() ? ps + 1 == n_pass : pl->seg_last[ps] != 0; };
@@ -796,7 +930,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 HIP_TRY(hipEventRecord(e->fork_ev, e->stream));
                 HIP_TRY(hipStreamWaitEvent(e->stream2, e->fork_ev, 0));
             }
-            HIP_TRY(hipEventRecord(e->pass_ev[0], e->stream));
+            HIP_TRY(hipEventRecord(L->pass_ev[0], e->stream));
             // chain A: tile launches
             auto chain_a = [&]() -> int {
             for (uint32_t ci = 0; ci < TILE_CLASSES && !hrc && ca.n_tile_units > 0; ++ci) {
@@ -869,10 +1003,10 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
                 HIP_TRY(hipStreamWaitEvent(e->stream, e->join_ev, 0));
             }
             for (size_t ps = 1; ps < n_pass && ps < VJ_MAX_PASSES && ps <= first_joint_pass; ++ps)
-                HIP_TRY(hipEventRecord(e->pass_ev[ps], e->stream));
+                HIP_TRY(hipEventRecord(L->pass_ev[ps], e->stream));
             // joint passes
             for (size_t ps = first_joint_pass; ps < n_pass && !hrc; ++ps) {
-                if (ps > first_joint_pass && ps < VJ_MAX_PASSES) HIP_TRY(hipEventRecord(e->pass_ev[ps], e->stream));
+                if (ps > first_joint_pass && ps < VJ_MAX_PASSES) HIP_TRY(hipEventRecord(L->pass_ev[ps], e->stream));
                 CascadeArgs qa = queue_args(ps);
                 if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, e->stream))) return rc;
                 qa.stage_entered = launch_counters();
@@ -885,21 +1019,49 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             }
             launches = (int)n_pass;
         }
-        if (n_pass <= VJ_MAX_PASSES && launches) HIP_TRY(hipEventRecord(e->pass_ev[n_pass], e->stream));
-        HIP_TRY(hipEventRecord(e->ev[3], e->stream));
-        // read back the counters block
-        HIP_TRY(hipMemcpyAsync(e->h_pinned, e->d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
-        HIP_TRY(hipStreamSynchronize(e->stream));
-        const uint32_t n_det = ((const uint32_t*)e->h_pinned)[MAX_PASSES * q_counts];
+        if (n_pass <= VJ_MAX_PASSES && launches) HIP_TRY(hipEventRecord(L->pass_ev[n_pass], e->stream));
+        HIP_TRY(hipEventRecord(L->ev[3], e->stream));
+        L->launches = launches;
+    }
+    L->n_pass = n_pass;
+    L->count = count;
+    // read back the counters block and the first detections (nearly always all of them)
+    HIP_TRY(hipMemcpyAsync(L->h_pinned, L->d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
+    const size_t room = (L->h_pinned_bytes - ((counts_bytes + 255) & ~(size_t)255)) / sizeof(DetEntry);
+    L->det_copied = (uint32_t)std::min<size_t>(room, L->det_cap);
+    HIP_TRY(hipMemcpyAsync((char*)L->h_pinned + ((counts_bytes + 255) & ~(size_t)255), L->d_det.p, (size_t)L->det_copied * sizeof(DetEntry),
+                           hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipEventRecord(L->done, e->stream));
+    L->pending = true;
+    return VJ_OK;
+}
+
+// Wait for the batch on lane L and decode it: detections appended to `dets` with frame numbers offset by f0.  When the
+// detection buffer overflowed it is grown and the cascade passes run again on the integral images, which are still in
+// place (a stream refuses a new batch while one is being redone: it is finished synchronously here).
+static int finish_batch(vj_env* e, Lane* L, Plan* pl, int f0, int W, int H, const vj_params& p, std::vector<RawDet>* dets,
+                        vj_counters* ctr, vj_timing* tm, std::vector<DetEntry>* raw_out = nullptr) {
+    int rc;
+    constexpr size_t q_counts = CountsLayout::q_counts;
+    const size_t counts_bytes = CountsLayout::bytes;
+    for (int attempt = 0; attempt < 3; ++attempt) {
+        HIP_TRY(hipEventSynchronize(L->done));
+        L->pending = false;
+        const size_t n_pass = L->n_pass;
+        const int launches = L->launches;
+        const bool count = L->count;
+        const std::vector<vj_launch>& linfo = L->linfo;
+        const uint32_t n_det = ((const uint32_t*)L->h_pinned)[MAX_PASSES * q_counts];
         float ms_i = 0, ms_c = 0, ms_t = 0;
-        HIP_TRY(hipEventElapsedTime(&ms_i, e->ev[0], e->ev[1]));
-        HIP_TRY(hipEventElapsedTime(&ms_c, e->ev[2], e->ev[3]));
-        HIP_TRY(hipEventElapsedTime(&ms_t, e->ev[0], e->ev[3]));
-        if (n_det > e->det_cap) {  // detections overflowed: grow and redo the cascade passes
-            uint32_t want = e->det_cap;
+        HIP_TRY(hipEventElapsedTime(&ms_i, L->ev[0], L->ev[1]));
+        HIP_TRY(hipEventElapsedTime(&ms_c, L->ev[2], L->ev[3]));
+        HIP_TRY(hipEventElapsedTime(&ms_t, L->ev[0], L->ev[3]));
+        if (n_det > L->det_cap) {  // detections overflowed: grow and redo the cascade passes
+            uint32_t want = L->det_cap;
             while (want < n_det) want *= 2;
-            if ((rc = e->d_det.ensure((size_t)want * sizeof(DetEntry)))) return rc;
-            e->det_cap = want;
+            if ((rc = L->d_det.ensure((size_t)want * sizeof(DetEntry)))) return rc;
+            L->det_cap = want;
+            if ((rc = enqueue_cascade(e, L, pl, W, H, p))) return rc;
             continue;
         }
         if (attempt == 0) tm->integral_ms += ms_i;
@@ -908,21 +1070,21 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         if (launches && n_pass <= VJ_MAX_PASSES)
             for (size_t ps = 0; ps < n_pass; ++ps) {
                 float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, e->pass_ev[ps], e->pass_ev[ps + 1]));
+                HIP_TRY(hipEventElapsedTime(&ms, L->pass_ev[ps], L->pass_ev[ps + 1]));
                 tm->pass_ms[ps] += ms;
                 tm->pass_stage_begin[ps] = (int32_t)pl->pass_bounds[ps];
                 tm->pass_stage_end[ps] = (int32_t)pl->pass_bounds[ps + 1];
             }
         tm->n_cascade_launches = std::max(tm->n_cascade_launches, launches);
+        const unsigned long long* se_all = (const unsigned long long*)((const uint32_t*)L->h_pinned + CountsLayout::stage_off_u32);
         if (linfo.size() <= VJ_MAX_LAUNCHES) {
             for (size_t i = 0; i < linfo.size(); ++i) {
                 float ms = 0;
-                HIP_TRY(hipEventElapsedTime(&ms, e->launch_ev[2 * i], e->launch_ev[2 * i + 1]));
+                HIP_TRY(hipEventElapsedTime(&ms, L->launch_ev[2 * i], L->launch_ev[2 * i + 1]));
                 vj_launch acc = tm->launch[i];   // sums over sub-batches: time and counters
                 tm->launch[i] = linfo[i];
                 tm->launch[i].ms = acc.ms + ms;
-                const unsigned long long* se = (const unsigned long long*)((const uint32_t*)e->h_pinned +
-                                                                           MAX_PASSES * q_counts + 2) + (1 + i) * VJ_MAX_STAGES;
+                const unsigned long long* se = se_all + (1 + i) * VJ_MAX_STAGES;
                 for (size_t s = 0; s < (size_t)VJ_MAX_STAGES; ++s)
                     tm->launch[i].stage_entered[s] = acc.stage_entered[s] + (count ? se[s] : 0ull);
             }
@@ -930,8 +1092,7 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
         }
 #ifdef VJ_STAMPS
         if (getenv("VJ_DEBUG_STAMPS")) {  // diagnostic build (-DVJ_STAMPS=1): phase cycle sums of the tile kernel
-            const unsigned long long* se =
-                (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * q_counts + 2);
+            const unsigned long long* se = se_all;
             for (size_t l = 0; l < linfo.size(); ++l)
                 fprintf(stderr, "vj launch %zu kind %d class %d: max resident workgroups %llu\n", l, linfo[l].kind, linfo[l].lds_class,
                         se[(1 + l) * VJ_MAX_STAGES + 39]);
@@ -944,14 +1105,15 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             fprintf(stderr, "\n");
         }
 #endif
-        if (count) {
-            const unsigned long long* se =
-                (const unsigned long long*)((const uint32_t*)e->h_pinned + MAX_PASSES * q_counts + 2);
+        if (count)
             for (size_t s = 0; s < pl->stages.size(); ++s)
-                for (int l = 1; l <= VJ_MAX_LAUNCHES; ++l) ctr->stage_entered[s] += se[(size_t)l * VJ_MAX_STAGES + s];
-        }
+                for (int l = 1; l <= VJ_MAX_LAUNCHES; ++l) ctr->stage_entered[s] += se_all[(size_t)l * VJ_MAX_STAGES + s];
         std::vector<DetEntry> raw(n_det);
-        if (n_det) HIP_TRY(hipMemcpy(raw.data(), e->d_det.p, (size_t)n_det * sizeof(DetEntry), hipMemcpyDeviceToHost));
+        const uint32_t have = std::min(n_det, L->det_copied);
+        if (have) memcpy(raw.data(), (const char*)L->h_pinned + ((counts_bytes + 255) & ~(size_t)255), (size_t)have * sizeof(DetEntry));
+        if (n_det > have)
+            HIP_TRY(hipMemcpy(raw.data() + have, (const DetEntry*)L->d_det.p + have, (size_t)(n_det - have) * sizeof(DetEntry),
+                              hipMemcpyDeviceToHost));
         const uint32_t stride = (uint32_t)W + 1u;
         const uint64_t fbytes = (uint64_t)pl->frame_elems * 4u;
         for (const DetEntry& d : raw) {
@@ -959,10 +1121,99 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
             const uint32_t el = (uint32_t)((d.off - (uint64_t)f * fbytes) / 4u);
             dets->push_back(RawDet{f0 + (int)f, d.scale, el % stride, el / stride});
         }
+        if (raw_out) *raw_out = std::move(raw);
         return VJ_OK;
     }
     set_error("detection buffer overflow persisted");
     return VJ_ERR_LIMIT;
+}
+
+// One sub-batch: frames [f0, f0+nf).  Appends decoded detections to `dets`.
+static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, int nf, int W, int H,
+                           const vj_params& p, std::vector<RawDet>* dets, vj_counters* ctr, vj_timing* tm) {
+    int rc;
+    Lane* L = &e->lane0;
+    if ((rc = enqueue_prepare(e, L, pl, frames + f0, nf, W, H, false, nullptr))) return rc;
+    if ((rc = enqueue_cascade(e, L, pl, W, H, p))) return rc;
+    return finish_batch(e, L, pl, f0, W, H, p, dets, ctr, tm);
+}
+
+// Sort, widen and (optionally) group the decoded detections of a whole call; fill the counters.
+static int build_result(Plan* pl, std::vector<RawDet>& dets, int n_frames, const vj_params& p, vj_result* out) {
+    // deterministic order: (frame, scale_idx, y, x)
+    std::sort(dets.begin(), dets.end(), [](const RawDet& a, const RawDet& b) {
+        return std::tie(a.frame, a.slot, a.y, a.x) < std::tie(b.frame, b.slot, b.y, b.x);
+    });
+    out->count = (uint32_t)dets.size();
+    if (!dets.empty()) {
+        out->rects = (vj_rect*)malloc(dets.size() * sizeof(vj_rect));
+        if (!out->rects) return VJ_ERR_NOMEM;
+        for (size_t i = 0; i < dets.size(); ++i) {
+            const vj_scale_info& si = pl->scales_info[dets[i].slot];
+            out->rects[i] = vj_rect{(int32_t)dets[i].x, (int32_t)dets[i].y, si.win_w, si.win_h, 0.0f, dets[i].frame,
+                                    si.scale_idx};
+        }
+    }
+    if (p.min_neighbors != 0 && out->count) {  // clod.cpp:1325-1326: filterResult(matches, n, MAX(min_neighbors, 1), EPS)
+        const int rc = vj_group_rectangles(out->rects, &out->count, (int)std::max<uint32_t>(p.min_neighbors, 1u), 0.2);
+        if (rc) return rc;
+    }
+    if (p.flags & VJ_FLAG_COUNTERS) {
+        vj_counters& k = out->counters;
+        k.windows = pl->windows_per_frame * (uint64_t)n_frames;
+        uint64_t rect_evals = 0;
+        for (size_t s = 0; s < pl->stages.size(); ++s) {
+            // exact for stump cascades; for multi-node trees this is the upper bound
+            // (every node of every tree) — see DESIGN.md
+            k.stump_evals += k.stage_entered[s] * pl->prog.n_nodes[s];
+            rect_evals += k.stage_entered[s] * pl->prog.n_rects[s];
+        }
+        k.gather_bytes = 48ull * k.windows + 16ull * rect_evals;
+    }
+    return VJ_OK;
+}
+
+// Frames per sub-batch so that 32-bit byte offsets into the batch sum image never wrap and the worst-case survivor
+// queues stay within a fixed budget.
+static uint64_t max_frames_per_subbatch(const vj_env* e, const Plan* pl) {
+    const uint64_t frame_bytes = (uint64_t)pl->frame_elems * 4u;
+    uint64_t max_frames = (0xffffffffull - (uint64_t)pl->max_reach_elems * 4u - 16u) / frame_bytes;
+    const uint64_t q_budget = 6ull << 30;  // bytes per queue
+    // a queue holds Q_PARTS parts of ceil(frames / Q_PARTS) frames' worth of windows each (layout_queues)
+    auto fit_parts = [](uint64_t frames_worth) {
+        return frames_worth >= Q_PARTS ? frames_worth / Q_PARTS * Q_PARTS : std::max<uint64_t>(1, frames_worth);
+    };
+    if (pl->windows_per_frame) {
+        max_frames = std::min<uint64_t>(max_frames, fit_parts(q_budget / (pl->windows_per_frame * sizeof(QEntry))));
+        max_frames = std::min<uint64_t>(max_frames, fit_parts(0xffffffffull / pl->windows_per_frame));
+    }
+    if (e->max_subbatch > 0) max_frames = std::min<uint64_t>(max_frames, (uint64_t)e->max_subbatch);
+    return max_frames;
+}
+
+static int check_frames(const vj_image* frames, int n_frames, int* W_, int* H_, int* CH_) {
+    const int W = frames[0].width, H = frames[0].height;
+    if (W <= 0 || H <= 0) return VJ_ERR_ARG;
+    const int CH = image_channels(frames[0]);
+    if (CH != 1 && CH != 3 && CH != 4) {
+        set_error("frames must have 1 (gray), 3 (BGR) or 4 (BGRA) channels");
+        return VJ_ERR_ARG;
+    }
+    for (int i = 0; i < n_frames; ++i) {
+        if (!frames[i].data || frames[i].width != W || frames[i].height != H || image_channels(frames[i]) != CH ||
+            frames[i].stride < W * CH) {
+            set_error("frame %d: all frames of a batch must be non-null and of equal size and channel count", i);
+            return VJ_ERR_ARG;
+        }
+    }
+    if ((uint64_t)(W + 1) * (uint64_t)(H + 3) >= (1ull << 30)) {
+        set_error("image too large");
+        return VJ_ERR_LIMIT;
+    }
+    *W_ = W;
+    *H_ = H;
+    *CH_ = CH;
+    return VJ_OK;
 }
 
 }  // namespace vj
@@ -996,15 +1247,15 @@ int vj_env_create(int device_index, vj_env** out) {
         return VJ_ERR_NO_DEVICE;
     }
     e->n_cu = prop.multiProcessorCount;
+    if (const int hrc = prepare_tile_kernels()) {
+        set_error("raising the dynamic LDS limit on device %d failed: %s", device_index, hipGetErrorString((hipError_t)hrc));
+        return VJ_ERR_HIP;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
-    for (auto& ev : e->ev) HIP_TRY(hipEventCreate(&ev));
-    for (auto& ev : e->pass_ev) HIP_TRY(hipEventCreate(&ev));
-    for (auto& ev : e->launch_ev) HIP_TRY(hipEventCreate(&ev));
+    { const int lrc = e->lane0.create(); if (lrc) return lrc; }
     HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
     HIP_TRY(hipEventCreateWithFlags(&e->join_ev, hipEventDisableTiming));
     HIP_TRY(hipStreamCreateWithFlags(&e->stream2, hipStreamNonBlocking));
-    e->h_pinned_bytes = 65536;
-    HIP_TRY(hipHostMalloc(&e->h_pinned, e->h_pinned_bytes, hipHostMallocDefault));
     if (const char* s = getenv("VJ_BLOCKS_PER_CU")) e->blocks_per_cu = std::max(1, atoi(s));
     if (const char* s = getenv("VJ_PASS_SPLIT")) {  // e.g. "4,9,15"
         for (const char* q = s; *q;) {
@@ -1024,17 +1275,11 @@ void vj_env_destroy(vj_env* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     drop_plans(e);
-    for (DevBuf* b : {&e->d_gray, &e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_counts,
-                      &e->d_det})
+    for (DevBuf* b : {&e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_tilted, &e->d_out,
+                      &e->d_skip_bits, &e->d_rois, &e->d_roi_units, &e->d_roi_det})
         b->release();
+    e->lane0.destroy();
     for (DevBuf& b : e->d_q) b.release();
-    if (e->h_pinned) (void)hipHostFree(e->h_pinned);
-    for (auto& ev : e->ev)
-        if (ev) (void)hipEventDestroy(ev);
-    for (auto& ev : e->pass_ev)
-        if (ev) (void)hipEventDestroy(ev);
-    for (auto& ev : e->launch_ev)
-        if (ev) (void)hipEventDestroy(ev);
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
     if (e->join_ev) (void)hipEventDestroy(e->join_ev);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
@@ -1049,14 +1294,7 @@ int vj_env_device_name(const vj_env* e, char* buf, size_t cap) {
 }
 
 static void drop_plans(vj_env* e) {
-    for (auto& kv : e->plans) {
-        kv.second->d_table.release();
-        kv.second->d_scales.release();
-        kv.second->d_stages.release();
-        kv.second->d_units.release();
-        kv.second->d_tile_units.release();
-        kv.second->d_sp_blocks.release();
-    }
+    for (auto& kv : e->plans) kv.second->release_device();
     e->plans.clear();
 }
 
@@ -1174,6 +1412,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         drop_plans(e);
         return VJ_OK;
     }
+    if (strcmp(key, "plan_cache_max") == 0) {
+        e->plan_cache_max = std::max(1, atoi(value));
+        return VJ_OK;
+    }
     if (strcmp(key, "max_subbatch") == 0) {
         e->max_subbatch = std::max(0, atoi(value));
         return VJ_OK;
@@ -1186,7 +1428,7 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         }
         HIP_TRY(hipStreamSynchronize(e->stream));
         e->det_cap_init = (uint32_t)v;
-        e->det_cap = 0;
+        e->lane0.det_cap = 0;
         return VJ_OK;
     }
     if (strcmp(key, "concurrent_blocks_per_cu") == 0) {
@@ -1290,6 +1532,85 @@ int vj_integral_image(vj_env* e, const vj_image* image, uint32_t* sum, uint64_t*
     return VJ_OK;
 }
 
+static int check_single_image(const vj_image* image, int* ch_out) {
+    const int w = image->width, h = image->height, ch = image_channels(*image);
+    if (w <= 0 || h <= 0 || (ch != 1 && ch != 3 && ch != 4) || image->stride < w * ch) return VJ_ERR_ARG;
+    if ((uint64_t)(w + 1) * (uint64_t)(h + 3) >= (1ull << 30)) {
+        set_error("image too large");
+        return VJ_ERR_LIMIT;
+    }
+    *ch_out = ch;
+    return VJ_OK;
+}
+
+int vj_integral_tilted(vj_env* e, const vj_image* image, uint32_t* tilted) {
+    if (!e || !image || !image->data || !tilted) return VJ_ERR_ARG;
+    int ch, rc;
+    if ((rc = check_single_image(image, &ch))) return rc;
+    const int w = image->width, h = image->height;
+    HIP_TRY(hipSetDevice(e->device));
+    if ((rc = ensure_image_buffers(e, w, h, 1, true, ch))) return rc;
+    const uint8_t* d_gray;
+    size_t fb;
+    int gs;
+    if ((rc = stage_frames(e, image, 1, w, h, &d_gray, &fb, &gs))) return rc;
+    if ((rc = enqueue_tilted(e, d_gray, fb, gs, w, h, 1, ch))) return rc;
+    HIP_TRY(hipMemcpyAsync(tilted, e->d_tilted.p, (size_t)(w + 1) * (size_t)(h + 1) * 4, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return VJ_OK;
+}
+
+int vj_grayscale(vj_env* e, const vj_image* image, uint8_t* gray, int gray_stride) {
+    if (!e || !image || !image->data || !gray || gray_stride < image->width) return VJ_ERR_ARG;
+    int ch, rc;
+    if ((rc = check_single_image(image, &ch))) return rc;
+    const int w = image->width, h = image->height;
+    HIP_TRY(hipSetDevice(e->device));
+    if ((rc = ensure_image_buffers(e, w, h, 1, true, ch))) return rc;
+    const uint8_t* d_src;
+    size_t fb;
+    int gs;
+    if ((rc = stage_frames(e, image, 1, w, h, &d_src, &fb, &gs))) return rc;
+    const size_t pitch = ((size_t)w + 3) & ~(size_t)3;
+    if ((rc = e->d_out.ensure(pitch * (size_t)h))) return rc;
+    TiltedArgs ta;
+    memset(&ta, 0, sizeof(ta));
+    ta.gray = d_src;
+    ta.gray_frame_bytes = fb;
+    ta.gray_stride = (uint32_t)gs;
+    ta.channels = (uint32_t)ch;
+    ta.width = (uint32_t)w;
+    ta.height = (uint32_t)h;
+    ta.n_frames = 1;
+    const int hrc = launch_grayscale(ta, (uint8_t*)e->d_out.p, (uint32_t)pitch, e->stream);
+    if (hrc) {
+        set_error("grayscale launch failed: %s", hipGetErrorString((hipError_t)hrc));
+        return VJ_ERR_HIP;
+    }
+    HIP_TRY(hipMemcpy2DAsync(gray, (size_t)gray_stride, e->d_out.p, pitch, (size_t)w, (size_t)h, hipMemcpyDeviceToHost, e->stream));
+    HIP_TRY(hipStreamSynchronize(e->stream));
+    return VJ_OK;
+}
+
+int vj_host_alloc(vj_env* e, size_t bytes, void** out) {
+    if (!e || !out || bytes == 0) return VJ_ERR_ARG;
+    *out = nullptr;
+    HIP_TRY(hipSetDevice(e->device));
+    const hipError_t he = hipHostMalloc(out, bytes, hipHostMallocDefault);
+    if (he != hipSuccess) {
+        set_error("hipHostMalloc(%zu) failed: %s", bytes, hipGetErrorString(he));
+        *out = nullptr;
+        return he == hipErrorOutOfMemory ? VJ_ERR_NOMEM : VJ_ERR_HIP;
+    }
+    return VJ_OK;
+}
+
+void vj_host_free(vj_env* e, void* p) {
+    if (!e || !p) return;
+    (void)hipSetDevice(e->device);
+    (void)hipHostFree(p);
+}
+
 int vj_integral(vj_env* e, const uint8_t* gray, int w, int h, int stride, uint32_t* sum, uint64_t* sqsum) {
     if (!e || !gray || !sum || !sqsum || w <= 0 || h <= 0 || stride < w) return VJ_ERR_ARG;
     vj_image im{gray, w, h, stride, 0, 1};
@@ -1305,43 +1626,18 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
         set_error("scale_factor must be > 1");
         return VJ_ERR_ARG;
     }
-    const int W = frames[0].width, H = frames[0].height;
-    if (W <= 0 || H <= 0) return VJ_ERR_ARG;
-    const int CH = image_channels(frames[0]);
-    if (CH != 1 && CH != 3 && CH != 4) {
-        set_error("frames must have 1 (gray), 3 (BGR) or 4 (BGRA) channels");
+    if ((p->flags & VJ_FLAG_SKIP_LIST) && (p->flags & VJ_FLAG_SKIP_ROW)) {
+        set_error("VJ_FLAG_SKIP_LIST and VJ_FLAG_SKIP_ROW are two different loops of the reference: pick one");
         return VJ_ERR_ARG;
     }
-    for (int i = 0; i < n_frames; ++i) {
-        if (!frames[i].data || frames[i].width != W || frames[i].height != H || image_channels(frames[i]) != CH ||
-            frames[i].stride < W * CH) {
-            set_error("frame %d: all frames of a batch must be non-null and of equal size and channel count", i);
-            return VJ_ERR_ARG;
-        }
-    }
-    if ((uint64_t)(W + 1) * (uint64_t)(H + 3) >= (1ull << 30)) {
-        set_error("image too large");
-        return VJ_ERR_LIMIT;
-    }
+    int W, H, CH;
+    int rc = check_frames(frames, n_frames, &W, &H, &CH);
+    if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
     Plan* pl;
-    int rc = get_plan(e, c, W, H, *p, &pl);
+    rc = get_plan(e, c, W, H, *p, &pl);
     if (rc) return rc;
-
-    // Sub-batch so that 32-bit byte offsets into the batch sum image never wrap and the
-    // worst-case survivor queues stay within a fixed budget.
-    const uint64_t frame_bytes = (uint64_t)pl->frame_elems * 4u;
-    uint64_t max_frames = (0xffffffffull - (uint64_t)pl->max_reach_elems * 4u - 16u) / frame_bytes;
-    const uint64_t q_budget = 6ull << 30;  // bytes per queue
-    // a queue holds Q_PARTS parts of ceil(frames / Q_PARTS) frames' worth of windows each (layout_queues)
-    auto fit_parts = [](uint64_t frames_worth) {
-        return frames_worth >= Q_PARTS ? frames_worth / Q_PARTS * Q_PARTS : std::max<uint64_t>(1, frames_worth);
-    };
-    if (pl->windows_per_frame) {
-        max_frames = std::min<uint64_t>(max_frames, fit_parts(q_budget / (pl->windows_per_frame * sizeof(QEntry))));
-        max_frames = std::min<uint64_t>(max_frames, fit_parts(0xffffffffull / pl->windows_per_frame));
-    }
-    if (e->max_subbatch > 0) max_frames = std::min<uint64_t>(max_frames, (uint64_t)e->max_subbatch);
+    const uint64_t max_frames = max_frames_per_subbatch(e, pl);
     if (max_frames == 0) {
         set_error("a single frame exceeds the 32-bit offset range");
         return VJ_ERR_LIMIT;
@@ -1352,37 +1648,7 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
         rc = detect_subbatch(e, pl, frames, f0, nf, W, H, *p, &dets, &out->counters, &out->timing);
         if (rc) return rc;
     }
-    // deterministic order: (frame, scale_idx, y, x)
-    std::sort(dets.begin(), dets.end(), [](const RawDet& a, const RawDet& b) {
-        return std::tie(a.frame, a.slot, a.y, a.x) < std::tie(b.frame, b.slot, b.y, b.x);
-    });
-    out->count = (uint32_t)dets.size();
-    if (!dets.empty()) {
-        out->rects = (vj_rect*)malloc(dets.size() * sizeof(vj_rect));
-        if (!out->rects) return VJ_ERR_NOMEM;
-        for (size_t i = 0; i < dets.size(); ++i) {
-            const vj_scale_info& si = pl->scales_info[dets[i].slot];
-            out->rects[i] = vj_rect{(int32_t)dets[i].x, (int32_t)dets[i].y, si.win_w, si.win_h, 0.0f, dets[i].frame,
-                                    si.scale_idx};
-        }
-    }
-    if (p->min_neighbors != 0 && out->count) {  // clod.cpp:1325-1326: filterResult(matches, n, MAX(min_neighbors, 1), EPS)
-        rc = vj_group_rectangles(out->rects, &out->count, (int)std::max<uint32_t>(p->min_neighbors, 1u), 0.2);
-        if (rc) return rc;
-    }
-    if (p->flags & VJ_FLAG_COUNTERS) {
-        vj_counters& k = out->counters;
-        k.windows = pl->windows_per_frame * (uint64_t)n_frames;
-        uint64_t rect_evals = 0;
-        for (size_t s = 0; s < pl->stages.size(); ++s) {
-            // exact for stump cascades; for multi-node trees this is the upper bound
-            // (every node of every tree) — see DESIGN.md
-            k.stump_evals += k.stage_entered[s] * pl->prog.n_nodes[s];
-            rect_evals += k.stage_entered[s] * pl->prog.n_rects[s];
-        }
-        k.gather_bytes = 48ull * k.windows + 16ull * rect_evals;
-    }
-    return VJ_OK;
+    return build_result(pl, dets, n_frames, *p, out);
 }
 
 // Second cascade on regions of interest (config 5: eyes inside faces).  A ROI is a view —
@@ -1447,6 +1713,335 @@ int vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int n
         memcpy(out->rects, all.data(), all.size() * sizeof(vj_rect));
     }
     return VJ_OK;
+}
+
+
+// ------------------------------------------------------------------ two cascades, hand-off on the device
+int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second, const vj_image* frames, int n_frames,
+                    const vj_params* p_first, const vj_params* p_second, vj_result* out_first, vj_result* out_second) {
+    if (!e || !first || !second || !p_first || !p_second || !out_first || !out_second || n_frames < 0 || (n_frames > 0 && !frames))
+        return VJ_ERR_ARG;
+    memset(out_first, 0, sizeof(*out_first));
+    memset(out_second, 0, sizeof(*out_second));
+    if (n_frames == 0) return VJ_OK;
+    if (!(p_first->scale_factor > 1.0f) || !(p_second->scale_factor > 1.0f)) {
+        set_error("scale_factor must be > 1");
+        return VJ_ERR_ARG;
+    }
+    if (p_first->min_neighbors != 0 || (p_first->flags | p_second->flags) & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW) ||
+        (p_second->scale_mask[0] | p_second->scale_mask[1]) != 0) {
+        set_error("vj_detect_chain hands RAW candidates over on the device: min_neighbors of the first cascade, the skip modes and a "
+                  "scale mask on the second cascade are not supported");
+        return VJ_ERR_UNSUPPORTED;
+    }
+    int W, H, CH;
+    int rc = check_frames(frames, n_frames, &W, &H, &CH);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(e->device));
+    Plan *pl1, *pl2;
+    if ((rc = get_plan(e, first, W, H, *p_first, &pl1))) return rc;
+    // the second cascade is planned for the frame's stride and every scale a region as large as the frame could use;
+    // each region picks its own scales and grid on the device
+    if ((rc = get_plan(e, second, W, H, *p_second, &pl2))) return rc;
+    if ((rc = get_plan(e, first, W, H, *p_first, &pl1))) return rc;   // (the cache may have evicted it for pl2: look it up again)
+    if (pl2->general) {
+        set_error("the second cascade of vj_detect_chain must be a linear cascade");
+        return VJ_ERR_UNSUPPORTED;
+    }
+    const uint64_t max_frames = std::min(max_frames_per_subbatch(e, pl1), max_frames_per_subbatch(e, pl2));
+    if (max_frames == 0) {
+        set_error("a single frame exceeds the 32-bit offset range");
+        return VJ_ERR_LIMIT;
+    }
+    {   // the second plan's scale records go to the device with a queue layout (none is used by the region pass)
+        uint64_t dummy = 0;
+        if (pl2->frames_q == 0 && (rc = layout_queues(pl2, 1, &dummy))) return rc;
+    }
+    Lane* L = &e->lane0;
+    std::vector<RawDet> dets1;
+    struct Det2 { int roi; uint32_t slot, x, y; };
+    std::vector<Det2> dets2;
+    const bool count2 = (p_second->flags & VJ_FLAG_COUNTERS) != 0;
+    const uint32_t stride = (uint32_t)W + 1u;
+    const uint64_t fbytes = (uint64_t)pl1->frame_elems * 4u;
+    for (int f0 = 0; f0 < n_frames; f0 += (int)max_frames) {
+        const int nf = (int)std::min<uint64_t>(max_frames, (uint64_t)(n_frames - f0));
+        if ((rc = enqueue_prepare(e, L, pl1, frames + f0, nf, W, H, false, nullptr))) return rc;
+        if (e->roi_unit_cap == 0) e->roi_unit_cap = 1u << 18;
+        if (e->roi_det_cap == 0) e->roi_det_cap = 1u << 16;
+        uint32_t n_det1 = 0, n_units = 0, n_det2 = 0;
+        float ms_roi = 0;
+        bool ok = false;
+        for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
+            if ((rc = enqueue_cascade(e, L, pl1, W, H, *p_first))) return rc;
+            if ((rc = e->d_rois.ensure((size_t)L->det_cap * sizeof(RoiDev)))) return rc;
+            if ((rc = e->d_roi_units.ensure((size_t)e->roi_unit_cap * sizeof(RoiUnit)))) return rc;
+            if ((rc = e->d_roi_det.ensure((size_t)e->roi_det_cap * sizeof(RoiDet)))) return rc;
+            uint32_t* roi_counts = (uint32_t*)L->d_counts.p + CountsLayout::roi_off_u32;   // zeroed with the block by enqueue_cascade
+            RoiArgs ra;
+            memset(&ra, 0, sizeof(ra));
+            ra.det_in = (const DetEntry*)L->d_det.p;
+            ra.det_in_count = (const uint32_t*)L->d_counts.p + MAX_PASSES * CountsLayout::q_counts;
+            ra.det_in_cap = L->det_cap;
+            ra.scales_in = (const ScaleDev*)pl1->d_scales.p;
+            ra.frame_bytes = pl1->frame_elems * 4u;
+            ra.stride = stride;
+            ra.rois = (RoiDev*)e->d_rois.p;
+            ra.n_rois = roi_counts + 0;
+            ra.max_rois = L->det_cap;
+            ra.n_frames = (uint32_t)nf;
+            ra.frame_w = W;
+            ra.frame_h = H;
+            ra.win_w0 = second->win_w;
+            ra.win_h0 = second->win_h;
+            ra.units = (RoiUnit*)e->d_roi_units.p;
+            ra.n_units = roi_counts + 1;   // (+2: invalid regions)
+            ra.max_units = e->roi_unit_cap;
+            ra.ticket = roi_counts + 3;
+            ra.det = (RoiDet*)e->d_roi_det.p;
+            ra.det_count = roi_counts + 4;
+            ra.det_cap = e->roi_det_cap;
+            CascadeArgs ca;
+            memset(&ca, 0, sizeof(ca));
+            ca.sum = (const uint32_t*)e->d_sum.p;
+            ca.sqsum = (const uint64_t*)e->d_sqsum.p;
+            ca.table = (const uint32_t*)pl2->d_table.p;
+            ca.scales = (const ScaleDev*)pl2->d_scales.p;
+            ca.stages = (const StageDev*)pl2->d_stages.p;
+            ca.n_frames = (uint32_t)nf;
+            ca.n_scales = (uint32_t)pl2->scales.size();
+            ca.frame_elems = pl2->frame_elems;
+            ca.sum_bytes = (uint32_t)((uint64_t)pl2->frame_elems * 4u * (uint64_t)nf);
+            ca.stride = stride;
+            ca.stage_begin = 0;
+            ca.stage_end = (uint32_t)pl2->stages.size();
+            ca.identity_order = 1u;
+            ca.tree2 = 0u;
+            ca.signed_mean = (p_second->flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
+            ca.stage_entered = (unsigned long long*)(roi_counts + 8);
+            HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], e->stream));
+            const int hrc = launch_roi_chain(ra, ca, true, pl2->trees, count2, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
+            if (hrc) {
+                set_error("region pass launch failed: %s", hipGetErrorString((hipError_t)hrc));
+                return VJ_ERR_HIP;
+            }
+            HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 1], e->stream));
+            // the region counters join the block enqueue_cascade already copies; copy them again now that they are final
+            HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32, roi_counts, (8 + (size_t)VJ_MAX_STAGES * 2) * 4,
+                                   hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipEventRecord(L->done, e->stream));
+            HIP_TRY(hipEventSynchronize(L->done));
+            const uint32_t* hc = (const uint32_t*)L->h_pinned;
+            n_det1 = hc[MAX_PASSES * CountsLayout::q_counts];
+            n_units = hc[CountsLayout::roi_off_u32 + 1];
+            n_det2 = hc[CountsLayout::roi_off_u32 + 4];
+            if (hc[CountsLayout::roi_off_u32 + 2] != 0) {
+                set_error("internal error: %u regions outside their frames", hc[CountsLayout::roi_off_u32 + 2]);
+                return VJ_ERR_HIP;
+            }
+            if (n_det1 > L->det_cap) {   // as finish_batch would: grow, and run both cascades again
+                uint32_t want = L->det_cap;
+                while (want < n_det1) want *= 2;
+                if ((rc = L->d_det.ensure((size_t)want * sizeof(DetEntry)))) return rc;
+                L->det_cap = want;
+                continue;
+            }
+            if (n_units > e->roi_unit_cap || n_det2 > e->roi_det_cap) {
+                while (e->roi_unit_cap < n_units) e->roi_unit_cap *= 2;
+                while (e->roi_det_cap < n_det2) e->roi_det_cap *= 2;
+                continue;
+            }
+            HIP_TRY(hipEventElapsedTime(&ms_roi, L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], L->launch_ev[2 * VJ_MAX_LAUNCHES - 1]));
+            ok = true;
+        }
+        if (!ok) {
+            set_error("region buffers kept overflowing");
+            return VJ_ERR_LIMIT;
+        }
+        // first cascade: decode (device order kept in raw1 for the region numbers)
+        const size_t base1 = dets1.size();
+        std::vector<DetEntry> raw1;
+        if ((rc = finish_batch(e, L, pl1, f0, W, H, *p_first, &dets1, &out_first->counters, &out_first->timing, &raw1))) return rc;
+        // second cascade
+        std::vector<RoiDet> raw2(n_det2);
+        if (n_det2) HIP_TRY(hipMemcpy(raw2.data(), e->d_roi_det.p, (size_t)n_det2 * sizeof(RoiDet), hipMemcpyDeviceToHost));
+        for (const RoiDet& d : raw2) {
+            const uint32_t f = (uint32_t)(d.off / fbytes);
+            const uint32_t el = (uint32_t)((d.off - (uint64_t)f * fbytes) / 4u);
+            const RawDet& r1 = dets1[base1 + d.roi];
+            dets2.push_back(Det2{(int)(base1 + d.roi), d.slot, el % stride - r1.x, el / stride - r1.y});
+        }
+        out_second->timing.cascade_ms += ms_roi;
+        out_second->timing.total_ms += ms_roi;
+        out_second->timing.n_cascade_launches = 1;
+        if (count2) {
+            const unsigned long long* se = (const unsigned long long*)((const uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 8);
+            for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) out_second->counters.stage_entered[s2] += se[s2];
+        }
+    }
+    // the first result in its sorted order; regions are numbered by their position in it
+    std::vector<uint32_t> order(dets1.size());
+    for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
+    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+        return std::tie(dets1[a].frame, dets1[a].slot, dets1[a].y, dets1[a].x) < std::tie(dets1[b].frame, dets1[b].slot, dets1[b].y, dets1[b].x);
+    });
+    std::vector<uint32_t> rank(dets1.size());
+    for (size_t i = 0; i < order.size(); ++i) rank[order[i]] = (uint32_t)i;
+    if ((rc = build_result(pl1, dets1, n_frames, *p_first, out_first))) return rc;
+    std::sort(dets2.begin(), dets2.end(), [&](const Det2& a, const Det2& b) {
+        return std::make_tuple(rank[a.roi], a.slot, a.y, a.x) < std::make_tuple(rank[b.roi], b.slot, b.y, b.x);
+    });
+    out_second->count = (uint32_t)dets2.size();
+    if (!dets2.empty()) {
+        out_second->rects = (vj_rect*)malloc(dets2.size() * sizeof(vj_rect));
+        if (!out_second->rects) return VJ_ERR_NOMEM;
+        for (size_t i = 0; i < dets2.size(); ++i) {
+            const vj_scale_info& si = pl2->scales_info[dets2[i].slot];
+            out_second->rects[i] = vj_rect{(int32_t)dets2[i].x, (int32_t)dets2[i].y, si.win_w, si.win_h, 0.0f, (int32_t)rank[dets2[i].roi],
+                                           si.scale_idx};
+        }
+    }
+    if (p_second->min_neighbors != 0 && out_second->count) {
+        rc = vj_group_rectangles(out_second->rects, &out_second->count, (int)std::max<uint32_t>(p_second->min_neighbors, 1u), 0.2);
+        if (rc) return rc;
+    }
+    if (count2) {
+        vj_counters& k = out_second->counters;
+        k.windows = k.stage_entered[0];
+        uint64_t rect_evals = 0;
+        for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) {
+            k.stump_evals += k.stage_entered[s2] * pl2->prog.n_nodes[s2];
+            rect_evals += k.stage_entered[s2] * pl2->prog.n_rects[s2];
+        }
+        k.gather_bytes = 48ull * k.windows + 16ull * rect_evals;
+    }
+    return VJ_OK;
+}
+
+// ------------------------------------------------------------------ frame streams
+struct vj_stream {
+    vj_env* e = nullptr;
+    vj_params p;
+    int W = 0, H = 0, CH = 1, max_batch = 0;
+    std::unique_ptr<Plan> plan;     // private: its queue layout must not change while a batch is in flight
+    Lane lanes[2];
+    hipStream_t copy = nullptr;
+    int fifo[2] = {0, 0};           // lanes holding submitted batches, oldest first
+    int n_pending = 0;
+    int n_frames_of[2] = {0, 0};
+};
+
+int vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int channels, int max_batch, const vj_params* p,
+                     vj_stream** out) {
+    if (!out) return VJ_ERR_ARG;
+    *out = nullptr;
+    if (!e || !c || !p || width <= 0 || height <= 0 || max_batch <= 0) return VJ_ERR_ARG;
+    const int CH = channels <= 1 ? 1 : channels;
+    if (CH != 1 && CH != 3 && CH != 4) return VJ_ERR_ARG;
+    if (!(p->scale_factor > 1.0f) || ((p->flags & VJ_FLAG_SKIP_LIST) && (p->flags & VJ_FLAG_SKIP_ROW))) return VJ_ERR_ARG;
+    if ((uint64_t)(width + 1) * (uint64_t)(height + 3) >= (1ull << 30)) {
+        set_error("image too large");
+        return VJ_ERR_LIMIT;
+    }
+    HIP_TRY(hipSetDevice(e->device));
+    auto s = std::make_unique<vj_stream>();
+    s->e = e;
+    s->p = *p;
+    s->W = width;
+    s->H = height;
+    s->CH = CH;
+    s->max_batch = max_batch;
+    s->plan = std::make_unique<Plan>();
+    struct Guard {   // releases what was created when a later step fails
+        vj_stream* s;
+        ~Guard() { if (s) vj_stream_destroy(s); }
+    } guard{nullptr};
+    int rc = build_plan(e, *c, width, height, *p, s->plan.get());
+    if (rc) {
+        s->plan->release_device();
+        return rc;
+    }
+    vj_stream* raw = s.release();
+    guard.s = raw;
+    if ((uint64_t)max_batch > max_frames_per_subbatch(e, raw->plan.get())) {
+        set_error("max_batch %d exceeds what one launch sequence can address at this frame size (%llu frames)", max_batch,
+                  (unsigned long long)max_frames_per_subbatch(e, raw->plan.get()));
+        return VJ_ERR_LIMIT;
+    }
+    for (Lane& L : raw->lanes)
+        if ((rc = L.create())) return rc;
+    HIP_TRY(hipStreamCreateWithFlags(&raw->copy, hipStreamNonBlocking));
+    // every buffer at its final size now: nothing is (re)allocated while batches are in flight
+    for (Lane& L : raw->lanes)
+        if ((rc = ensure_image_buffers(e, width, height, max_batch, true, CH, &L))) return rc;
+    uint64_t q_entries = 0;
+    if ((rc = layout_queues(raw->plan.get(), max_batch, &q_entries))) return rc;
+    const size_t n_pass = raw->plan->pass_bounds.size() - 1;
+    for (size_t ps = 1; ps < n_pass; ++ps)
+        if ((rc = e->d_q[ps].ensure(std::max<uint64_t>(q_entries, 1) * sizeof(QEntry)))) return rc;
+    guard.s = nullptr;
+    *out = raw;
+    return VJ_OK;
+}
+
+int vj_stream_submit(vj_stream* s, const vj_image* frames, int n_frames) {
+    if (!s || !frames || n_frames <= 0 || n_frames > s->max_batch) return VJ_ERR_ARG;
+    if (s->n_pending >= 2) {
+        set_error("two batches are pending: collect one before submitting the next");
+        return VJ_ERR_LIMIT;
+    }
+    int W, H, CH;
+    int rc = check_frames(frames, n_frames, &W, &H, &CH);
+    if (rc) return rc;
+    if (W != s->W || H != s->H || CH != s->CH) {
+        set_error("frames do not have the stream's size / channel count");
+        return VJ_ERR_ARG;
+    }
+    vj_env* e = s->e;
+    HIP_TRY(hipSetDevice(e->device));
+    const int lane = s->n_pending == 0 ? 0 : 1 - s->fifo[0];
+    Lane* L = &s->lanes[lane];
+    // the lane's frame buffer is free once the integral kernels of its previous batch have read it
+    HIP_TRY(hipEventSynchronize(L->integral_done));
+    if ((rc = enqueue_prepare(e, L, s->plan.get(), frames, n_frames, W, H, true, s->copy))) return rc;
+    if ((rc = enqueue_cascade(e, L, s->plan.get(), W, H, s->p))) return rc;
+    s->fifo[s->n_pending] = lane;
+    s->n_frames_of[lane] = n_frames;
+    s->n_pending++;
+    return VJ_OK;
+}
+
+int vj_stream_collect(vj_stream* s, vj_result* out) {
+    if (!s || !out) return VJ_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    if (s->n_pending == 0) {
+        set_error("no batch is pending");
+        return VJ_ERR_ARG;
+    }
+    vj_env* e = s->e;
+    HIP_TRY(hipSetDevice(e->device));
+    const int lane = s->fifo[0];
+    s->fifo[0] = s->fifo[1];
+    s->n_pending--;
+    Lane* L = &s->lanes[lane];
+    std::vector<RawDet> dets;
+    int rc = finish_batch(e, L, s->plan.get(), 0, s->W, s->H, s->p, &dets, &out->counters, &out->timing);
+    if (rc) return rc;
+    return build_result(s->plan.get(), dets, s->n_frames_of[lane], s->p, out);
+}
+
+void vj_stream_destroy(vj_stream* s) {
+    if (!s) return;
+    (void)hipSetDevice(s->e->device);
+    if (s->e->stream) (void)hipStreamSynchronize(s->e->stream);
+    if (s->e->stream2) (void)hipStreamSynchronize(s->e->stream2);
+    if (s->copy) {
+        (void)hipStreamSynchronize(s->copy);
+        (void)hipStreamDestroy(s->copy);
+    }
+    for (Lane& L : s->lanes) L.destroy();
+    if (s->plan) s->plan->release_device();
+    delete s;
 }
 
 void vj_result_free(vj_result* r) {

@@ -82,9 +82,50 @@ struct Plan {
     uint32_t n_order = 0;  // stages reachable from stage 0, in StageDev::order
     StageProgram prog;
     // device copies
-    DevBuf d_table, d_scales, d_stages, d_units, d_tile_units, d_sp_blocks;
+    DevBuf d_table, d_scales, d_stages, d_units, d_tile_units, d_sp_blocks, d_skip_units, d_skip_segs;
+    // P2 skip modes (VJ_FLAG_SKIP_LIST / VJ_FLAG_SKIP_ROW): bitmap geometry and work lists of the two bitmap kernels
+    uint32_t skip_mode = 0, skip_frame_words = 0, n_skip_units = 0, n_skip_segs = 0;
     uint32_t n_sp_blocks = 0;
     int frames_q = 0;  // frames the ScaleDev.q_base/q_cap currently describe
+    uint64_t last_used = 0;   // vj_env::plan_tick of the last call that used this plan (LRU eviction)
+    void release_device() {
+        for (DevBuf* b : {&d_table, &d_scales, &d_stages, &d_units, &d_tile_units, &d_sp_blocks, &d_skip_units, &d_skip_segs}) b->release();
+    }
+};
+
+}  // namespace vj
+
+namespace vj {
+
+struct LaunchNote {   // one kernel launch of the batch in flight, for vj_timing
+    vj_launch info;
+};
+
+// Everything ONE batch in flight owns: its frames on the device, its counters / detections and their host copies, and
+// the events that time it.  vj_detect uses the environment's own lane; a vj_stream owns two, so that the upload of
+// batch k+1 can run while the kernels of batch k do.  Integral images, survivor queues and plans are shared: the
+// kernels of successive batches are ordered on the environment's stream.
+struct Lane {
+    DevBuf d_gray, d_counts, d_det;
+    uint32_t det_cap = 0;
+    void* h_pinned = nullptr;        // counters block + the first detections, read back asynchronously
+    size_t h_pinned_bytes = 0;
+    void* h_stage = nullptr;         // pinned staging of pageable host frames (streams)
+    size_t h_stage_bytes = 0;
+    hipEvent_t ev[4] = {};
+    hipEvent_t pass_ev[VJ_MAX_PASSES + 1] = {};
+    hipEvent_t launch_ev[2 * VJ_MAX_LAUNCHES] = {};   // start/stop per launch
+    hipEvent_t upload_done = nullptr, integral_done = nullptr, done = nullptr;
+    // the batch in flight (enqueue_batch -> finish_batch)
+    bool pending = false;
+    int nf = 0, first_frame = 0;
+    size_t n_pass = 0;
+    int launches = 0;
+    bool count = false;
+    uint32_t det_copied = 0;         // detections already copied to h_pinned by the asynchronous read-back
+    std::vector<vj_launch> linfo;
+    int create();
+    void destroy();
 };
 
 }  // namespace vj
@@ -92,9 +133,7 @@ struct Plan {
 struct vj_env {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
-    hipEvent_t pass_ev[VJ_MAX_PASSES + 1] = {};
-    hipEvent_t launch_ev[2 * VJ_MAX_LAUNCHES] = {};   // start/stop per launch
+    vj::Lane lane0;                  // the batch of a plain vj_detect call
     hipEvent_t fork_ev = nullptr, join_ev = nullptr;
     hipStream_t stream2 = nullptr;   // second chain of the first part of the cascade
     int max_subbatch = 0;      // > 0: cap on frames per sub-batch (tests)
@@ -113,16 +152,22 @@ struct vj_env {
     char name[256] = "";
     int n_cu = 0;
     // image buffers
-    vj::DevBuf d_gray, d_sum, d_sqsum, d_band_sum, d_band_sq, d_band_sqp;
+    vj::DevBuf d_sum, d_sqsum, d_band_sum, d_band_sq, d_band_sqp;
+    vj::DevBuf d_tilted;            // tilted integral images (OpenCV profile, cascades with tilted features)
+    vj::DevBuf d_out;               // scratch for device -> host results (vj_grayscale)
     int slack_w = 0, slack_h = 0, slack_frames = 0;   // layout whose slack rows are known to be zero
     void *slack_sum = nullptr, *slack_sq = nullptr;
     // survivor queues + counters + detections
-    vj::DevBuf d_q[vj::MAX_PASSES], d_counts, d_det;   // d_q[p]: windows waiting to enter pass p (p >= 1)
-    uint32_t det_cap = 0;
-    void* h_pinned = nullptr;  // small pinned staging for counts
-    size_t h_pinned_bytes = 0;
-    typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t> PlanKey;
+    vj::DevBuf d_q[vj::MAX_PASSES];   // d_q[p]: windows waiting to enter pass p (p >= 1)
+    vj::DevBuf d_skip_bits;           // P2 skip modes: visited-window bitmaps of the frames in flight
+    vj::DevBuf d_rois, d_roi_units, d_roi_det;   // regions of interest on the device (vj_detect_chain)
+    uint32_t roi_unit_cap = 0, roi_det_cap = 0;
+    typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t, uint32_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<vj::Plan>> plans;
+    uint64_t plan_tick = 0;
+    int plan_cache_max = 48;      // plans kept per environment; the least recently used one is released beyond that
+                                  // (a stream of ROI sizes — eyes inside faces of any size — would otherwise grow
+                                  // device tables without bound)
     // tunables (env vars, read once)
     int blocks_per_cu = 8;
     int tile_class_kb[vj::TILE_CLASSES] = {-2, -1, 0};  // image-tile LDS budget per class in KiB; -k = what lets k
@@ -151,9 +196,10 @@ namespace vj {
 // image staging and the integral launches (vj_env.cpp)
 int image_channels(const vj_image& im);
 uint32_t frame_elems_for(int W, int H);
-int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_gray, int channels = 1);
+int ensure_image_buffers(vj_env* e, int W, int H, int frames, bool need_gray, int channels = 1, Lane* lane = nullptr);
 int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int stride, int W, int H, int frames,
                      int channels = 1);
 int stage_frames(vj_env* e, const vj_image* frames, int n, int W, int H, const uint8_t** d_ptr, size_t* frame_bytes,
-                 int* stride);
+                 int* stride, Lane* lane = nullptr, hipStream_t copy_stream = nullptr);
+int enqueue_tilted(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int stride, int W, int H, int frames, int channels);
 }  // namespace vj

@@ -36,6 +36,8 @@ struct StageProgram {
 enum { STAGE_ACCEPT = -1, STAGE_REJECT = -2 };
 
 StageProgram build_stage_program(const vj_cascade& c);
+// Sweep order of the stage graph (topological, rooted at stage 0); false when the links form a cycle.
+bool stage_sweep_order(const StageProgram& prog, std::vector<uint32_t>* order);
 
 // Enumerate scales exactly as clod.cpp:1198-1204 + setupScale (clod.cpp:371-415).
 std::vector<vj_scale_info> plan_scales(const vj_cascade& c, int width, int height,

@@ -253,6 +253,28 @@ int launch_integral(const IntegralArgs& a, void* stream_) {
 
 // ====================================================================== cascade
 
+// Window position of grid index i: precomputeWindows' lrint(i * step) (clod.cpp:514, half to even; the contract of the
+// OpenCL path) or the plain CPU loop's round(i * step) (clod.cpp:1416, half away from zero; VJ_FLAG_SKIP_ROW).
+__device__ __forceinline__ uint32_t window_pos(uint32_t i, float step, uint32_t round_away) {
+    const float v = (float)i * step;
+    return round_away != 0u ? (uint32_t)roundf(v) : (uint32_t)__float2int_rn(v);
+}
+
+// P2 skip modes: is grid window (ix, iy) of this scale one the reference's sequential loop visits?
+__device__ __forceinline__ bool window_visited(const CascadeArgs& a, uint32_t frame, uint32_t skip_base, uint32_t skip_wpr,
+                                               uint32_t nx, uint32_t ix, uint32_t iy) {
+    uint32_t word, bit;
+    if (skip_wpr != 0u) {
+        word = skip_base + iy * skip_wpr + (ix >> 6);
+        bit = ix & 63u;
+    } else {
+        const uint32_t i = iy * nx + ix;
+        word = skip_base + (i >> 6);
+        bit = i & 63u;
+    }
+    return ((a.skip_bits[(size_t)frame * a.skip_frame_words + word] >> bit) & 1ull) != 0ull;
+}
+
 // computeVariance (clod.cpp:418-446) for the window whose origin is element `e` of the
 // frame described by (sum_f, sq_f).
 __device__ __forceinline__ float window_variance(rsrc_t sum_f, rsrc_t sq_f, uint32_t e, uint32_t e_lt, uint32_t e_dw,
@@ -717,11 +739,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
                     iy = (first + i) / nx;
                     ix = first + i - iy * nx;
                 }
-                const bool valid = i < count && ix < nx && iy < ny;
+                bool valid = i < count && ix < nx && iy < ny;
+                if (a.skip_bits != nullptr && valid)   // uniform test
+                    valid = window_visited(a, frame, scales[slot].skip_base, scales[slot].skip_wpr, nx, ix, iy);
                 QEntry en{0u, 0.0f};
                 if (valid) {
-                    const uint32_t x = (uint32_t)__float2int_rn((float)ix * step);
-                    const uint32_t y = (uint32_t)__float2int_rn((float)iy * step);
+                    const uint32_t x = window_pos(ix, step, a.round_away);
+                    const uint32_t y = window_pos(iy, step, a.round_away);
                     const uint32_t e = y * a.stride + x;
                     en.var = window_variance(sum_f, sq_f, e, e_lt, e_dw, e_dh, area, a.signed_mean != 0u);
                     en.off = frame_bytes + e * 4u;
@@ -782,6 +806,231 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
             __builtin_amdgcn_wave_barrier();
         }
     }
+}
+
+
+// ------------------------------------------------------------------ P2: the windows the CPU variants visit
+// The reference's CPU loops are sequential: after a window that stage 0 rejects, the next one is not evaluated at
+// all (x_incr / subwindow_incr = 2: clod.cpp:1430 inside a row, :729-732 over the flattened list).  That is the
+// recurrence e[i] = !(e[i-1] && f[i-1]) with f = "stage 0 rejects"; a window that follows a non-reject is always
+// visited, so e[i] is the PARITY of the run of rejects that ends at i-1 — local information once f is known for every
+// grid window.  skip_fail_bits computes f (one 64-bit word per 64 consecutive windows), skip_resolve turns the words of
+// a recurrence domain (a row, or a scale's whole list) into visited bits; the cascade passes then drop unvisited
+// windows when they enumerate the grid.
+template <bool TREES>
+__global__ __launch_bounds__(256) void skip_fail_bits(CascadeArgs a) {
+    const uint32_t lane = lane_id();
+    const uint32_t rank = blockIdx.x * 4u + (threadIdx.x >> 6);
+    kptr<ScaleDev> scales = as_k(a.scales);
+    kptr<StageDev> stages = as_k(a.stages);
+    kptr<UnitDev> units = as_k(a.skip_units);
+    const uint32_t total = a.n_skip_units * a.n_frames;
+    const uint32_t frame_bytes4 = a.frame_elems * 4u;
+    const rsrc_t img = make_rsrc(a.sum, a.sum_bytes);
+    for (uint32_t u = rank; u < total; u += gridDim.x * 4u) {
+        const uint32_t frame = u / a.n_skip_units;
+        const uint32_t r = u - frame * a.n_skip_units;
+        const uint32_t slot = units[r].scale, first = units[r].first, count = units[r].count, word = units[r].bw;
+        const uint32_t nx = scales[slot].nx;
+        const float step = scales[slot].step;
+        uint32_t ix, iy;
+        if (scales[slot].skip_wpr != 0u) {
+            ix = (first & 0xffffu) + lane;
+            iy = first >> 16;
+        } else {
+            const uint32_t i = first + lane;
+            iy = i / nx;
+            ix = i - iy * nx;
+        }
+        bool fail = false;
+        if (lane < count) {
+            const size_t frame_off = (size_t)frame * a.frame_elems;
+            const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
+            const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
+            const uint32_t x = window_pos(ix, step, a.round_away), y = window_pos(iy, step, a.round_away);
+            const uint32_t e = y * a.stride + x;
+            const float var = window_variance(sum_f, sq_f, e, scales[slot].e_lt, scales[slot].e_dw, scales[slot].e_dh, scales[slot].area,
+                                              a.signed_mean != 0u);
+            kptr<NodeRecDev> tab = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + scales[slot].table_first + stages[0].first_node;
+            fail = !(stage_sum_of<TREES>(GlobalImg{img}, tab, stages[0].n_nodes, frame * frame_bytes4 + e * 4u, var) >= stages[0].threshold);
+        }
+        const unsigned long long F = __ballot(fail);
+        if (lane == 0) a.skip_bits[(size_t)frame * a.skip_frame_words + word] = F;
+    }
+}
+
+__global__ __launch_bounds__(256) void skip_resolve(CascadeArgs a) {
+    const uint32_t lane = lane_id();
+    const uint32_t rank = blockIdx.x * 4u + (threadIdx.x >> 6);
+    kptr<UnitDev> segs = as_k(a.skip_segs);
+    const uint32_t total = a.n_skip_segs * a.n_frames;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    for (uint32_t u = rank; u < total; u += gridDim.x * 4u) {
+        const uint32_t frame = u / a.n_skip_segs;
+        const uint32_t r = u - frame * a.n_skip_segs;
+        unsigned long long* words = a.skip_bits + (size_t)frame * a.skip_frame_words + segs[r].first;
+        const uint32_t n_words = segs[r].count;
+        uint32_t carry = 0;   // parity of the reject run that ends just before the chunk's first bit (the first window is visited)
+        for (uint32_t w0 = 0; w0 < n_words; w0 += 64u) {
+            const bool act = w0 + lane < n_words;
+            const unsigned long long F = act ? words[w0 + lane] : 0ull;   // bits past the domain's end are 0 (not rejects)
+            // a word of 64 rejects passes the parity through; any other word ends with a run whose parity is its own
+            const bool through = F == ~0ull;
+            const uint32_t tpar = (uint32_t)__clzll((long long)~F) & 1u;   // leading ones of F = the run that ends at bit 63
+            const unsigned long long m = __ballot(act && !through);
+            const unsigned long long lower = m & below;
+            const uint32_t src = lower != 0ull ? 63u - (uint32_t)__clzll((long long)lower) : 0u;
+            const uint32_t from_lane = (uint32_t)__shfl((int)tpar, (int)src, 64);
+            uint32_t p = lower != 0ull ? from_lane : carry;
+            unsigned long long V = 0ull;
+#pragma unroll 8
+            for (uint32_t b = 0; b < 64u; ++b) {
+                V |= (unsigned long long)(p ^ 1u) << b;             // visited when the run before it is even
+                p = ((F >> b) & 1ull) != 0ull ? p ^ 1u : 0u;        // run-length parity after this window
+            }
+            if (act) words[w0 + lane] = V;
+            if (m != 0ull) carry = (uint32_t)__shfl((int)tpar, 63 - __clzll((long long)m), 64);
+        }
+    }
+}
+
+int launch_skip_bitmap(const CascadeArgs& a, bool trees, int n_blocks, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (trees) hipLaunchKernelGGL(skip_fail_bits<true>, dim3(n_blocks), dim3(256), 0, stream, a);
+    else       hipLaunchKernelGGL(skip_fail_bits<false>, dim3(n_blocks), dim3(256), 0, stream, a);
+    hipLaunchKernelGGL(skip_resolve, dim3(n_blocks), dim3(256), 0, stream, a);
+    return (int)hipGetLastError();
+}
+
+
+// ------------------------------------------------------------------ regions of interest on the device
+// Two cascades back to back (BASELINE config 5): the raw candidates of a first cascade become regions
+// of interest without leaving the device, and a second cascade runs inside every region on the frame's OWN integral
+// images.  A rectangle sum is a four-corner difference, so it does not depend on where the integral image starts: a
+// region evaluated in place gives exactly what the reference would compute on the sub-image (its caller would pass
+// clodDetectObjects a sub-image header).  Every region lays out its own grid — setupScale (clod.cpp:371-415) for the
+// region's size, evaluated on the device with the same f32 operations as the host's plan_scales — and is cut into
+// units of <= UNIT_WINDOWS windows; persistent waves then draw units from a ticket counter and run the whole second
+// cascade on each with the compacting stage sweep of the global-gather passes.  No size-dependent host plan, no host
+// round trip between the cascades.
+
+__global__ __launch_bounds__(256) void dets_to_rois(RoiArgs r) {
+    const uint32_t n = min(*r.det_in_count, min(r.det_in_cap, r.max_rois));
+    kptr<ScaleDev> scales = as_k(r.scales_in);
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n; i += gridDim.x * 256u) {
+        const DetEntry d = r.det_in[i];
+        const uint32_t frame = d.off / r.frame_bytes;
+        const uint32_t el = (d.off - frame * r.frame_bytes) >> 2;
+        const uint32_t y = el / r.stride, x = el - y * r.stride;
+        r.rois[i] = RoiDev{(int32_t)frame, (int32_t)x, (int32_t)y, (int32_t)scales[d.scale].win_w, (int32_t)scales[d.scale].win_h};
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) *r.n_rois = n;
+}
+
+__global__ __launch_bounds__(256) void roi_plan_units(RoiArgs r, CascadeArgs a) {
+    const uint32_t n = min(*r.n_rois, r.max_rois);
+    kptr<ScaleDev> scales = as_k(a.scales);
+    const uint32_t total = n * a.n_scales;
+    for (uint32_t t = blockIdx.x * 256u + threadIdx.x; t < total; t += gridDim.x * 256u) {
+        const uint32_t roi = t / a.n_scales, slot = t - roi * a.n_scales;
+        const RoiDev R = r.rois[roi];
+        if (R.frame < 0 || (uint32_t)R.frame >= r.n_frames || R.x < 0 || R.y < 0 || R.w <= 0 || R.h <= 0 || R.x + R.w > r.frame_w ||
+            R.y + R.h > r.frame_h) {
+            if (slot == 0u) atomicAdd(r.n_units + 1, 1u);   // invalid regions are counted and reported by the host
+            continue;
+        }
+        const float cs = scales[slot].scale_f, step = scales[slot].step;
+        const int32_t win_w = (int32_t)scales[slot].win_w, win_h = (int32_t)scales[slot].win_h;
+        // scale enumeration (clod.cpp:1198-1204): the f32 chain s_k increases, so scale k is enumerated for this region
+        // exactly when its own test holds
+        if (!(cs * (float)r.win_w0 < (float)(R.w - 10) && cs * (float)r.win_h0 < (float)(R.h - 10))) continue;
+        // setupScale's rejections (clod.cpp:391-401); min / max limits were applied when the plan chose its scales
+        if (win_w > R.w || win_h > R.h) continue;
+        const int32_t nx = __float2int_rn((float)(R.w - win_w) / step);   // lrint of an int / float quotient (clod.cpp:409-412)
+        const int32_t ny = __float2int_rn((float)(R.h - win_h) / step);
+        if (nx <= 0 || ny <= 0) continue;
+        const uint32_t nwin = (uint32_t)nx * (uint32_t)ny;
+        const uint32_t nun = (nwin + UNIT_WINDOWS - 1u) / UNIT_WINDOWS;
+        const uint32_t base = atomicAdd(r.n_units, nun);
+        for (uint32_t j = 0; j < nun && base + j < r.max_units; ++j)
+            r.units[base + j] = RoiUnit{roi, slot, j * UNIT_WINDOWS, min((uint32_t)UNIT_WINDOWS, nwin - j * UNIT_WINDOWS), (uint32_t)nx, (uint32_t)ny};
+    }
+}
+
+template <bool TREES, bool COUNT>
+__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_roi_pass(RoiArgs r, CascadeArgs a) {
+    __shared__ QEntry lds_q[WAVES_PER_BLOCK * UNIT_WINDOWS];
+    const uint32_t lane = lane_id();
+    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    QEntry* q = lds_q + wib * UNIT_WINDOWS;
+    kptr<ScaleDev> scales = as_k(a.scales);
+    const rsrc_t img = make_rsrc(a.sum, a.sum_bytes);
+    const uint32_t n_units = min(*r.n_units, r.max_units);
+    const uint32_t frame_bytes4 = a.frame_elems * 4u;
+    while (true) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(r.ticket, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        if (t >= n_units) break;
+        const RoiUnit un = r.units[t];
+        const uint32_t roi = __builtin_amdgcn_readfirstlane(un.roi), slot = __builtin_amdgcn_readfirstlane(un.slot);
+        const uint32_t first = __builtin_amdgcn_readfirstlane(un.first), count = __builtin_amdgcn_readfirstlane(un.count);
+        const uint32_t nx = __builtin_amdgcn_readfirstlane(un.nx);
+        const RoiDev R = r.rois[roi];
+        const uint32_t frame = __builtin_amdgcn_readfirstlane((uint32_t)R.frame);
+        const uint32_t x0 = __builtin_amdgcn_readfirstlane((uint32_t)R.x), y0 = __builtin_amdgcn_readfirstlane((uint32_t)R.y);
+        const float step = scales[slot].step;
+        const uint32_t e_lt = scales[slot].e_lt, e_dw = scales[slot].e_dw, e_dh = scales[slot].e_dh;
+        const float area = scales[slot].area;
+        const size_t frame_off = (size_t)frame * a.frame_elems;
+        const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
+        const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
+        const uint32_t frame_bytes = frame * frame_bytes4;
+        uint32_t n_q = 0;
+        for (uint32_t i0 = 0; i0 < count; i0 += 64u) {
+            const bool valid = i0 + lane < count;
+            const uint32_t i = first + i0 + lane;
+            const uint32_t iy = i / nx, ix = i - iy * nx;
+            QEntry en{0u, 0.0f};
+            if (valid) {
+                // precomputeWindows (clod.cpp:495-527) inside the region: x = lrint(ix * step) from the region's origin
+                const uint32_t x = x0 + (uint32_t)__float2int_rn((float)ix * step);
+                const uint32_t y = y0 + (uint32_t)__float2int_rn((float)iy * step);
+                const uint32_t e = y * a.stride + x;
+                en.var = window_variance(sum_f, sq_f, e, e_lt, e_dw, e_dh, area, a.signed_mean != 0u);
+                en.off = frame_bytes + e * 4u;
+            }
+            const unsigned long long mask = __ballot(valid);
+            if (valid) q[n_q + mbcnt(mask)] = en;
+            n_q += (uint32_t)__popcll(mask);
+        }
+        __builtin_amdgcn_wave_barrier();
+        kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + scales[slot].table_first;
+        const uint32_t n = sweep_stages<TREES, COUNT>(a, GlobalImg{img}, table, q, n_q, lane, a.stage_begin, a.stage_end);
+        if (n != 0u) {
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(r.det_count, n);
+            g = __builtin_amdgcn_readfirstlane(g);
+            for (uint32_t i = lane; i < n; i += 64u)
+                if (g + i < r.det_cap) r.det[g + i] = RoiDet{q[i].off, slot, roi};
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_roi_chain(const RoiArgs& r, const CascadeArgs& a, bool from_dets, bool trees, bool count, int n_blocks, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    if (from_dets) hipLaunchKernelGGL(dets_to_rois, dim3(256), dim3(256), 0, stream, r);
+    hipLaunchKernelGGL(roi_plan_units, dim3(512), dim3(256), 0, stream, r, a);
+    dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
+    if (trees) {
+        if (count) hipLaunchKernelGGL((cascade_roi_pass<true, true>), g, b, 0, stream, r, a);
+        else       hipLaunchKernelGGL((cascade_roi_pass<true, false>), g, b, 0, stream, r, a);
+    } else {
+        if (count) hipLaunchKernelGGL((cascade_roi_pass<false, true>), g, b, 0, stream, r, a);
+        else       hipLaunchKernelGGL((cascade_roi_pass<false, false>), g, b, 0, stream, r, a);
+    }
+    return (int)hipGetLastError();
 }
 
 
@@ -1310,8 +1559,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
         const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
         // tile origin in the image: the first window's origin (same expression as below)
-        const uint32_t x0 = __builtin_amdgcn_readfirstlane((uint32_t)__float2int_rn((float)ix0 * step));
-        const uint32_t y0 = __builtin_amdgcn_readfirstlane((uint32_t)__float2int_rn((float)iy0 * step));
+        const uint32_t x0 = __builtin_amdgcn_readfirstlane(window_pos(ix0, step, a.round_away));
+        const uint32_t y0 = __builtin_amdgcn_readfirstlane(window_pos(iy0, step, a.round_away));
 
         __syncthreads();  // the previous tile's gathers are finished
         STAMP(0);
@@ -1377,11 +1626,13 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
             const uint32_t ty = t / tw, tx = t - ty * tw;
             const uint32_t iy = iy0 + ty, ix = ix0 + tx;
             w_valid[k] = t < t_end && iy < ny && ix < nx;
+            if (a.skip_bits != nullptr && w_valid[k])   // uniform test
+                w_valid[k] = window_visited(a, frame, scales[slot].skip_base, scales[slot].skip_wpr, nx, ix, iy);
             w_lo4[k] = 0u;
             w_q[k] = 0ull;
             if (w_valid[k]) {
-                const uint32_t x = (uint32_t)__float2int_rn((float)ix * step);
-                const uint32_t y = (uint32_t)__float2int_rn((float)iy * step);
+                const uint32_t x = window_pos(ix, step, a.round_away);
+                const uint32_t y = window_pos(iy, step, a.round_away);
                 // byte offset inside the tile (de-interleaved rows: window origins are even columns)
                 const uint32_t e = y * a.stride + x;
                 // unstaged blocks: byte offset in the batch sum image, as in cascade_pass
@@ -1567,17 +1818,23 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
     if (VJ_STAMPS && threadIdx.x == 0) atomicAdd(a.stage_entered + 38, ~0ull);
 }
 
+// The tile kernel uses up to the CU's whole 160 KiB of dynamic LDS; HIP caps a kernel at 64 KiB until the attribute
+// is raised, and the attribute belongs to the (function, device) pair: vj_env_create calls this once per environment,
+// with that environment's device current.
+int prepare_tile_kernels() {
+    const int max_lds = 160 * 1024;
+    const void* fns[] = {(const void*)cascade_tile_pass<false, false, true>, (const void*)cascade_tile_pass<false, true, true>,
+                         (const void*)cascade_tile_pass<true, false, true>,  (const void*)cascade_tile_pass<true, true, true>,
+                         (const void*)cascade_tile_pass<false, false, false>, (const void*)cascade_tile_pass<false, true, false>};
+    for (const void* f : fns) {
+        const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
+        if (e != hipSuccess) return (int)e;
+    }
+    return 0;
+}
+
 int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, bool staged, int n_blocks, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
-    static bool attr_set = false;
-    if (!attr_set) {  // allow more than the default 64 KiB of dynamic LDS
-        const int max_lds = 160 * 1024;
-        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<false, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<false, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<true, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        (void)hipFuncSetAttribute((const void*)cascade_tile_pass<true, true, true>, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
-        attr_set = true;
-    }
     dim3 g(n_blocks), b(TILE_WAVES * 64);
     const size_t lds = a.tile_lds_bytes;
     if (!staged) {   // unstaged blocks: stump cascades only (the host keeps tree cascades on cascade_pass)

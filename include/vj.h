@@ -83,6 +83,14 @@ int  vj_cascade_load_xml(const char* path, vj_cascade** out);
 /* Compact binary form shipped under clfacedetection_amd/data (*.vjc). */
 int  vj_cascade_load(const char* path, vj_cascade** out);
 int  vj_cascade_save(const vj_cascade* c, const char* path);
+/* A cascade the caller already holds in memory — the reference's callers get a CvHaarClassifierCascade*
+ * from cvLoad (main.cpp:36; struct layout tempcv.hpp:70-112) and hand it to clodDetectObjects unchanged
+ * (clod.h:72-81).  The arrays are copied and validated; stage `child` links are derived as
+ * icvReadHaarClassifier does (tempcv.cpp:2080-2083) when every child is -1.  INTEGRATION.md shows the
+ * CvHaarClassifierCascade -> arrays walk that keeps clodDetectObjects' signature.                       */
+int  vj_cascade_from_arrays(int win_w, int win_h, const vj_stage_desc* stages, int n_stages,
+                            const vj_tree_desc* trees, int n_trees, const vj_node_desc* nodes, int n_nodes,
+                            const float* alpha, int n_alpha, vj_cascade** out);
 void vj_cascade_free(vj_cascade* c);
 int  vj_cascade_get_info(const vj_cascade* c, vj_cascade_info* out);
 /* Read-only views into the flat arrays (valid until vj_cascade_free). */
@@ -100,6 +108,15 @@ enum {
                                        pixel sum read through int* (differs from
                                        the default unsigned read only when the
                                        sum >= 2^31)            */
+    /* The reference's CPU variants thin the window grid with a data-dependent skip ("P2");
+     * its OpenCL kernel — the default contract here, "P1" — evaluates every grid window.  Linear cascades. */
+    VJ_FLAG_SKIP_LIST    = 1u << 2, /* CLOD_PER_STAGE_ITERATIONS CPU variant (clod.cpp:1434-1482, runSubwindow
+                                       :681-734): after a stage-0 reject the next entry of the FLATTENED
+                                       row-major window list is not evaluated (:729-732; crosses row ends) */
+    VJ_FLAG_SKIP_ROW     = 1u << 3, /* plain CPU variant (clod.cpp:1409-1432): window positions are
+                                       round(index * step) — half away from zero (:1416) instead of
+                                       precomputeWindows' lrint (:514) — and the next window of the ROW is
+                                       skipped after a stage-0 reject (x_incr, :1430)                      */
 };
 
 typedef struct vj_params {
@@ -171,11 +188,23 @@ int  vj_env_configure(vj_env* e, const char* key, const char* value);
 int vj_integral(vj_env* e, const uint8_t* gray, int w, int h, int stride,
                 uint32_t* sum, uint64_t* sqsum);
 
+/* Page-locked host memory for frames (what clodInitBuffers / clifInitBuffers pre-allocate in the reference,
+ * clod.cpp:102-163): frames that live in it are uploaded by DMA without a staging copy.                  */
+int  vj_host_alloc(vj_env* e, size_t bytes, void** out);
+void vj_host_free(vj_env* e, void* p);
+
 /* ----------------------------------------------------------------- detect */
 struct vj_image;
 /* clifGrayscaleIntegral (clif.h:67-70, clif.cpp:326-335): gray conversion + both integrals of one image
  * (host or device pointer, 1 / 3 / 4 channels); outputs as vj_integral.                       */
 int  vj_integral_image(vj_env* e, const struct vj_image* image, uint32_t* sum, uint64_t* sqsum);
+/* clifGrayscale (clif.h:55-58, clif.cpp:226-271 -> cvCvtColor BGR2GRAY): the 8-bit gray image the integral
+ * kernels see, written to the HOST buffer `gray` (gray_stride bytes per row).  1-channel input is copied. */
+int  vj_grayscale(vj_env* e, const struct vj_image* image, uint8_t* gray, int gray_stride);
+/* The tilted integral cvIntegral(img, sum, sqsum, tilted) returns for cascades with tilted features
+ * (tempcv.cpp:1335, :743-750): (h+1) x (w+1) u32, tilted(X, Y) = sum of gray(x, y) over y < Y,
+ * |x - X + 1| <= Y - y - 1.  HOST output.                                                              */
+int  vj_integral_tilted(vj_env* e, const struct vj_image* image, uint32_t* tilted);
 typedef struct vj_image {
     const uint8_t* data;       /* 8-bit, interleaved channels                   */
     int32_t width, height;
@@ -243,12 +272,17 @@ void vj_result_free(vj_result* r);
 
 /* ------------------------------------------------ OpenCV arithmetic profile */
 /* cvHaarDetectObjects(image, cascade, storage, scale_factor, min_neighbors, flags = 0, min_size)
- * (call site main.cpp:145; scale-cascade path as tempcv.cpp:1188-1456 keeps it): f64 variance,
- * node and stage sums, stage threshold - 0.0001f, cvRound-ed rectangles and grid, ystep =
- * max(2, factor), the skip after a stage-0 reject, the window-touches-border rule.  Raw
- * candidates (min_neighbors = 0) or cv::groupRectangles.  Linear cascades only.
- * counters.windows = positions the sequential walk visits.  Parity: against the oracle's
- * restatement of the same lines — OpenCV itself cannot be run here (unpinned).              */
+ * (call site main.cpp:145; scale-cascade path as tempcv.cpp:1188-1456 keeps it, scalar branches —
+ * CV_HAAR_USE_SSE is commented out at :28-36): f64 variance and stage sums; node sums as
+ * cvRunHaarClassifierCascadeSum writes them — an f64 product per rectangle in stump stages flagged
+ * two_rects (:872-888), otherwise int * float, i.e. a BINARY32 product widened to double before it is
+ * accumulated (:907-911, icvEvalHidHaarClassifier :783-788); stage threshold - 0.0001f; cvRound-ed
+ * rectangles and grid; ystep = max(2, factor); the skip after a reject (stage 0 for linear cascades, any
+ * stage for stage trees, which return 0 on every reject: :834-861, :1163); the window-touches-border
+ * rule; stage trees; tilted features on the tilted integral (:731, :743-750).  Raw candidates
+ * (min_neighbors = 0) or cv::groupRectangles.  counters.windows = positions the sequential walk
+ * visits.  Parity: against the oracle's restatement of the same lines — OpenCV itself cannot be run
+ * here (unpinned).                                                                                */
 typedef struct vj_cv_params {
     int32_t  min_w, min_h;     /* minSize (0 = none)                              */
     double   scale_factor;     /* 1.1                                             */
@@ -266,6 +300,32 @@ int  vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, in
 typedef struct vj_roi { int32_t frame, x, y, w, h; } vj_roi;
 int  vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames,
                     const vj_roi* rois, int n_rois, const vj_params* p, vj_result* out);
+
+/* Two cascades back to back with the hand-off on the device (BASELINE config 5): `first`
+ * runs on the frames as vj_detect does; every raw candidate it finds becomes a region of interest in a
+ * DEVICE-resident list (built by a kernel from the detection buffer), and `second` runs on those regions
+ * reading the frames' integral images in place — rectangle sums over a region do not depend on where the
+ * integral image starts, so the result equals running `second` on the sub-image (vj_detect_rois) — before
+ * anything returns to the host.  out_first: as vj_detect (p_first->min_neighbors must be 0).  out_second:
+ * rect.frame = index of the region in out_first->rects, x / y relative to the region's origin.
+ * `second` must be a linear cascade (stumps or trees).                                                */
+int  vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second, const vj_image* frames,
+                     int n_frames, const vj_params* p_first, const vj_params* p_second, vj_result* out_first,
+                     vj_result* out_second);
+
+/* ------------------------------------------------------------ frame streams */
+/* Video-style use (the demo's per-frame loop, main.cpp:104-125): batches of host frames are uploaded into
+ * one of two device buffers by DMA on a copy stream while the kernels of the previous batch run, and the
+ * results come back one submit later.  submit() returns once the batch is queued (it blocks only while
+ * both buffers are busy); collect() returns the oldest submitted batch (VJ_ERR_ARG when none is pending).
+ * Frames must stay valid until their batch is collected; put them in vj_host_alloc memory for a copy-free
+ * upload (pageable memory works, through a staging copy).  Results equal vj_detect's.                   */
+typedef struct vj_stream vj_stream;
+int  vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int channels, int max_batch,
+                      const vj_params* p, vj_stream** out);
+int  vj_stream_submit(vj_stream* s, const vj_image* frames, int n_frames);
+int  vj_stream_collect(vj_stream* s, vj_result* out);
+void vj_stream_destroy(vj_stream* s);
 
 /* filterResult (clod.cpp:182-357) as cv::groupRectangles defines it (tempcv.cpp:130-243): groups
  * `rects` (sorted by frame; grouped per frame, in place), keeps classes with more than

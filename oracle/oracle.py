@@ -210,7 +210,8 @@ class _OcCascade(C.Structure):
                 ("stage_parent", C.c_void_p), ("stage_next", C.c_void_p), ("stage_child", C.c_void_p),
                 ("tree_first_node", C.c_void_p), ("tree_n_nodes", C.c_void_p), ("tree_first_alpha", C.c_void_p),
                 ("node_rect", C.c_void_p), ("node_weight", C.c_void_p), ("node_threshold", C.c_void_p),
-                ("node_left", C.c_void_p), ("node_right", C.c_void_p), ("alpha", C.c_void_p)]
+                ("node_left", C.c_void_p), ("node_right", C.c_void_p), ("alpha", C.c_void_p),
+                ("node_tilted", C.c_void_p)]
 
 
 class OcScale(C.Structure):
@@ -253,6 +254,10 @@ class Oracle:
         L.oc_detect_opencvlike.argtypes = [C.POINTER(_OcCascade), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                            C.c_double, C.c_void_p, C.c_int, C.POINTER(C.c_int), C.POINTER(_OcStats)]
         L.oc_detect_opencvlike.restype = C.c_int
+        L.oc_detect_opencvlike_all_f64.argtypes = L.oc_detect_opencvlike.argtypes
+        L.oc_detect_opencvlike_all_f64.restype = C.c_int
+        L.oc_integral_tilted.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        L.oc_integral_tilted.restype = None
         L.oc_bgr2gray.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int]
         L.oc_bgr2gray.restype = None
         L.oc_group_rectangles.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_double, C.c_void_p]
@@ -272,6 +277,12 @@ class Oracle:
             a = np.ascontiguousarray(getattr(c, f), np.float32)
             keep.append(a)
             setattr(s, f, a.ctypes.data)
+        t = np.ascontiguousarray(c.node_tilted, np.int32)
+        if len(t) == c.n_nodes and t.any():
+            keep.append(t)
+            s.node_tilted = t.ctypes.data
+        else:
+            s.node_tilted = None
         return s, keep
 
     # a1
@@ -284,6 +295,14 @@ class Oracle:
         q = np.zeros((h + 1, w + 1), np.float64)
         self.lib.oc_integral(g.ctypes.data, w, h, g.strides[0], s.ctypes.data, q.ctypes.data)
         return s.view(np.uint32), q.astype(np.uint64)
+
+    def integral_tilted(self, gray: np.ndarray) -> np.ndarray:
+        """cvIntegral's tilted sum, (h+1, w+1) uint32 (32-bit wrap-around)."""
+        h, w = gray.shape
+        g = np.ascontiguousarray(gray)
+        t = np.zeros((h + 1, w + 1), np.int32)
+        self.lib.oc_integral_tilted(g.ctypes.data, w, h, g.strides[0], t.ctypes.data)
+        return t.view(np.uint32)
 
     # a2 + a3
     def plan_scales(self, c: CascadeArrays, W: int, H: int, min_size=(0, 0), max_size=(0, 0),
@@ -321,7 +340,7 @@ class Oracle:
         linear = bool(np.all(c.stage_next == -1))
         if mode is None:
             mode = 0 if linear else 1
-        assert mode == 1 or linear, "mode 0 (per-stage lists) is defined for linear cascades only"
+        assert mode == 1 or linear, "modes 0, 2, 3 (the reference's own loops) are defined for linear cascades only"
         out = np.zeros(cap, _RECT_DT)
         n_total = C.c_int(0)
         st = _OcStats()
@@ -345,17 +364,19 @@ class Oracle:
         return out
 
     def detect_opencvlike(self, c: CascadeArrays, gray: np.ndarray, min_size=(0, 0), scale_factor: float = 1.1,
-                          cap: int = 1 << 20):
-        """cvHaarDetectObjects' scale-cascade path per tempcv.cpp (f64 sums, threshold bias, stage-0 skip):
-        a TIMED baseline only, not a parity target.  Returns (rects, stats)."""
+                          cap: int = 1 << 20, all_f64: bool = False):
+        """cvHaarDetectObjects' scale-cascade path per tempcv.cpp (f64 stage sums over int * float node products,
+        f64 products in two_rects stump stages, threshold bias, skip after a reject, stage trees, tilted features):
+        the timed CPU baseline and the checker of vj_detect_opencv.  Returns (rects, stats)."""
         h, w = gray.shape
         g = np.ascontiguousarray(gray)
         s, keep = self._cstruct(c)
         out = np.zeros(cap, _RECT_DT)
         n_total = C.c_int(0)
         st = _OcStats()
-        n = self.lib.oc_detect_opencvlike(C.byref(s), g.ctypes.data, w, h, g.strides[0], min_size[0], min_size[1],
-                                          float(scale_factor), out.ctypes.data, cap, C.byref(n_total), C.byref(st))
+        fn = self.lib.oc_detect_opencvlike_all_f64 if all_f64 else self.lib.oc_detect_opencvlike   # all_f64: NOT the reference
+        n = fn(C.byref(s), g.ctypes.data, w, h, g.strides[0], min_size[0], min_size[1],
+               float(scale_factor), out.ctypes.data, cap, C.byref(n_total), C.byref(st))
         return out[:n], {"windows": int(st.windows), "stump_evals": int(st.stump_evals),
                          "stage_entered": [int(v) for v in st.stage_entered[:c.n_stages]]}
 

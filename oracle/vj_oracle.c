@@ -48,6 +48,7 @@ typedef struct oc_cascade {
     const int32_t* node_left;      /* >0 node index, <=0 -> alpha[-v]           */
     const int32_t* node_right;
     const float*   alpha;
+    const int32_t* node_tilted;    /* n_nodes, != 0: <tilted>1 (NULL = none); only the OpenCV-like path reads it */
 } oc_cascade;
 
 typedef struct oc_scale {
@@ -298,6 +299,14 @@ static float stage_sum_for(const oc_cascade* c, const k_node* kn, const uint32_t
  *  mode 1: per-window walk of the stage tree (tempcv.cpp:834-861): pass -> child,
  *          fail -> climb parents until a next sibling exists, else reject; falling
  *          off the end accepts.  Works for linear cascades too (child = next stage).
+ *  mode 2: the CPU per-stage-list variant (CLOD_PER_STAGE_ITERATIONS, clod.cpp:1434-1482 with
+ *          runSubwindow :681-734): mode 0 plus `subwindow_incr = 2` after a stage-0 reject (:729-732) — the
+ *          skip runs over the FLATTENED row-major window list, so it crosses row ends.  Linear cascades.
+ *  mode 3: the plain CPU per-window variant (clod.cpp:1409-1432 with runCascade :736-787): positions are
+ *          (cl_uint)round(index * step) — half away from zero, not precomputeWindows' lrint (:1416 vs :514)
+ *          — and `x_incr = exit_stage != 0 ? 1 : 2` (:1430) skips the next window of the ROW after a stage-0
+ *          reject; every row starts at its first window.  Linear cascades.
+ *          In modes 2 and 3 stage_entered[0] counts the windows actually visited (P2 of SURVEY.md §8a-8).
  * Returns the number of rects written (at most cap; the true count is in *n_total). */
 int oc_detect(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride,
               int min_w, int min_h, int max_w, int max_h, float scale_factor,
@@ -325,18 +334,53 @@ int oc_detect(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride
         const size_t nwin = (size_t)(sc.nx > 0 ? sc.nx : 0) * (size_t)(sc.ny > 0 ? sc.ny : 0);
         if (nwin == 0) continue;
         k_window* a = (k_window*)malloc(sizeof(k_window) * nwin);
+        if (mode == 3) {
+            /* clod.cpp:1409-1432: x_incr is declared before the row loop, but every row's for-statement starts
+             * again at start_point.x, so only the increments inside a row use it */
+            st->windows += nwin;
+            unsigned x_incr = 1;
+            for (int y_index = 0; y_index < sc.ny; y_index++) {
+                for (int x_index = 0; x_index < sc.nx; x_index += (int)x_incr) {
+                    k_window w;
+                    w.x = (uint32_t)round(x_index * sc.step);   /* int * float -> float, round(): half away */
+                    w.y = (uint32_t)round(y_index * sc.step);
+                    w.variance = compute_variance(sum, sqsum, iw, &sc, w.x, w.y, signed_mean);
+                    w.offset = iw * w.y + w.x;
+                    int exit_stage = 1;   /* runCascade, clod.cpp:736-787 */
+                    for (int stage = 0; stage < c->n_stages; ++stage) {
+                        st->stage_entered[stage]++;
+                        float stage_sum = stage_sum_for(c, kn, ii, &w, stage, st);
+                        if (stage_sum < c->stage_threshold[stage]) { exit_stage = -stage; break; }
+                    }
+                    if (exit_stage > 0) {
+                        if (found < cap) {
+                            out[found].x = (int32_t)w.x; out[found].y = (int32_t)w.y;
+                            out[found].w = sc.win_w; out[found].h = sc.win_h; out[found].scale_idx = scale_index;
+                        }
+                        found++;
+                    }
+                    x_incr = exit_stage != 0 ? 1 : 2;
+                }
+            }
+            free(a);
+            continue;
+        }
         uint32_t n_in = precompute_windows(sum, sqsum, iw, &sc, signed_mean, a);
         st->windows += n_in;
-        if (mode == 0) {
+        if (mode == 0 || mode == 2) {
             k_window* b = (k_window*)malloc(sizeof(k_window) * nwin);
             uint32_t n_out = n_in;
             for (int stage = 0; stage < c->n_stages; ++stage) {
-                st->stage_entered[stage] += n_in;
+                if (!(mode == 2 && stage == 0)) st->stage_entered[stage] += n_in;
                 n_out = 0;
                 const float thr = c->stage_threshold[stage];
-                for (uint32_t g = 0; g < n_in; ++g) {
+                uint32_t subwindow_incr = 1;   /* runSubwindow, clod.cpp:700-733 */
+                for (uint32_t g = 0; g < n_in; g += subwindow_incr) {
                     float stage_sum = stage_sum_for(c, kn, ii, &a[g], stage, st);
+                    subwindow_incr = 1;
+                    if (mode == 2 && stage == 0) st->stage_entered[0]++;
                     if (stage_sum >= thr) b[n_out++] = a[g];
+                    else if (mode == 2 && stage == 0) subwindow_incr = 2;
                 }
                 k_window* t = a; a = b; b = t;
                 n_in = n_out;
@@ -507,27 +551,111 @@ int oc_group_rectangles(oc_grect* rects, int n, int groupThreshold, double eps, 
 /* Restatement of cvHaarDetectObjects' scale-cascade path as the reference keeps it in tempcv.cpp
  * (a private copy of OpenCV 2.4.2 objdetect/haar.cpp, not part of the reference's build):
  *   driver loop                       tempcv.cpp:1330-1417  (double factor, ystep = max(2, factor), cvRound)
- *   cvSetImagesForHaarClassifierCascade   :549-768          (cvRound-ed rects, float weights, CV_ADJUST_WEIGHTS = 0)
- *   cvRunHaarClassifierCascadeSum      :795-972             (f64 sums, border rule :817-820)
+ *   icvCreateHidHaarClassifierCascade  :307-536             (isStumpBased, is_tree, per-stage two_rects :421, :458)
+ *   cvSetImagesForHaarClassifierCascade   :549-768          (cvRound-ed rects, float weights, CV_ADJUST_WEIGHTS = 0,
+ *                                                            tilted rectangles :743-750 with correction 0.5 :731)
+ *   icvEvalHidHaarClassifier           :771-792             (tree walk; int * float products)
+ *   cvRunHaarClassifierCascadeSum      :795-972             (border rule :817-820; three evaluation paths)
  *   stage threshold bias               :262, :419           (threshold - 0.0001f)
  *   ScaleCascade invoker               :1116-1185           (ixstep = result != 0 ? 1 : 2)
+ * CV_HAAR_USE_SSE is commented out in tempcv.cpp (:28-36), so the scalar branches are the specification:
+ *   - stump cascade, no stage tree, stage flagged two_rects (:872-888): `double rect0 = calc_sum(..);
+ *     rect0 *= weight;` — an f64 product per rectangle, `sum = rect1 + rect0`;
+ *   - every other stump stage (:907-911) and icvEvalHidHaarClassifier (:783-788): `calc_sum(..) * weight`
+ *     is int * float, i.e. a BINARY32 product ((float)int rounds above 2^24), widened to double afterwards
+ *     and accumulated in f64.
+ * calc_sum is int arithmetic (sumtype = int; wraps like the hardware does).
  * This is the "reference CPU path (OpenCV cv::CascadeClassifier ...)" north_star asks to be TIMED as a
- * baseline.  It is NOT a parity target: its arithmetic differs from the clod path on purpose, OpenCV itself
+ * baseline, and the checker of the library's OpenCV arithmetic profile (vj_detect_opencv).  OpenCV itself
  * is not installable here, so nothing pins it (SURVEY.md §8c "parity unpinned at the OpenCV boundary").   */
 typedef struct cv_rectp { int p0, p1, p2, p3; float weight; } cv_rectp;
-typedef struct cv_node { cv_rectp rect[3]; int nrect; float threshold; } cv_node;
+typedef struct cv_node { cv_rectp rect[3]; int nrect; int tilted; float threshold; } cv_node;
 
 static inline int cv_round(double v) { return (int)lrint(v); }
 
-int oc_detect_opencvlike(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride,
-                         int min_w, int min_h, double scaleFactor,
+/* The tilted integral cvIntegral returns next to sum (OpenCV 2.4.2 imgproc, not in the reference tree; its
+ * documented definition: tilted(X, Y) = sum of image(x, y) over y < Y, abs(x - X + 1) <= Y - y - 1), an
+ * (h+1) x (w+1) CV_32S matrix with a zero first row.  Computed with the row recurrence
+ *   T[Y][X] = T[Y-1][X-1] + T[Y-1][X+1] - T[Y-2][X] + I(X-1, Y-1) + I(X-1, Y-2)
+ * where T[Y][-1] = T[Y-1][0] and T[Y][w+1] = T[Y-1][w] (the triangle's apex lies outside the image);
+ * tests/test_oracle_cv.py checks it against the definition by brute force.  32-bit wrap-around.           */
+void oc_integral_tilted(const uint8_t* gray, int w, int h, int stride, int32_t* tilted) {
+    const int sw = w + 1;
+    uint32_t* T = (uint32_t*)tilted;
+    for (int x = 0; x <= w; ++x) T[x] = 0;
+    for (int Y = 1; Y <= h; ++Y) {
+        const uint32_t* t1 = T + (size_t)(Y - 1) * sw;                     /* row Y-1 */
+        const uint32_t* t2 = Y >= 2 ? T + (size_t)(Y - 2) * sw : NULL;      /* row Y-2 */
+        uint32_t* row = T + (size_t)Y * sw;
+        const uint8_t* i1 = gray + (size_t)(Y - 1) * stride;
+        const uint8_t* i2 = Y >= 2 ? gray + (size_t)(Y - 2) * stride : NULL;
+        for (int X = 0; X <= w; ++X) {
+            const uint32_t left = X >= 1 ? t1[X - 1] : (t2 ? t2[0] : 0u);
+            const uint32_t right = X + 1 <= w ? t1[X + 1] : (t2 ? t2[w] : 0u);
+            const uint32_t up2 = t2 ? t2[X] : 0u;
+            const uint32_t px = X >= 1 ? (uint32_t)i1[X - 1] + (i2 ? (uint32_t)i2[X - 1] : 0u) : 0u;
+            row[X] = left + right - up2 + px;
+        }
+    }
+}
+
+static inline int cv_calc_sum(const int32_t* img, int po, const cv_rectp* r) {
+    /* calc_sum(rect, offset) = p0[offset] - p1[offset] - p2[offset] + p3[offset], sumtype int */
+    return (int)((uint32_t)img[po + r->p0] - (uint32_t)img[po + r->p1] - (uint32_t)img[po + r->p2] + (uint32_t)img[po + r->p3]);
+}
+
+/* icvEvalHidHaarClassifier's node sum (tempcv.cpp:783-788), also the non-two_rects stump stages (:907-911) */
+static int g_all_f64 = 0;   /* test hook, see detect_opencvlike_impl */
+static inline double cv_node_sum_f32(const int32_t* sum, const int32_t* tilted, int po, const cv_node* k) {
+    const int32_t* img = k->tilted ? tilted : sum;
+    if (g_all_f64) {
+        double s = (double)cv_calc_sum(img, po, &k->rect[0]) * (double)k->rect[0].weight;
+        s += (double)cv_calc_sum(img, po, &k->rect[1]) * (double)k->rect[1].weight;
+        if (k->nrect > 2) s += (double)cv_calc_sum(img, po, &k->rect[2]) * (double)k->rect[2].weight;
+        return s;
+    }
+    double s = (double)((float)cv_calc_sum(img, po, &k->rect[0]) * k->rect[0].weight);
+    s += (double)((float)cv_calc_sum(img, po, &k->rect[1]) * k->rect[1].weight);
+    if (k->nrect > 2) s += (double)((float)cv_calc_sum(img, po, &k->rect[2]) * k->rect[2].weight);
+    return s;
+}
+
+/* all_f64 != 0 is NOT the reference: it multiplies every rectangle in f64 (what round 1 of this repo did by
+ * mistake).  It exists so that tests can show the literal arithmetic matters (tests/test_oracle_cv.py).   */
+static int detect_opencvlike_impl(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride,
+                         int min_w, int min_h, double scaleFactor, int all_f64,
                          oc_rect* out, int cap, int* n_total, oc_stats* st) {
     const int sw = W + 1;
     int32_t* sum = (int32_t*)calloc((size_t)sw * (H + 3), sizeof(int32_t));
     double* sqsum = (double*)calloc((size_t)sw * (H + 3), sizeof(double));
+    int32_t* tilted = NULL;
     cv_node* kn = (cv_node*)malloc(sizeof(cv_node) * (size_t)c->n_nodes);
     memset(st, 0, sizeof(*st));
+    g_all_f64 = all_f64;
     oc_integral(gray, W, H, stride, sum, sqsum);
+    /* icvCreateHidHaarClassifierCascade: cascade-wide and per-stage flags (tempcv.cpp:410-470) */
+    int is_stump_based = 1, is_tree = 0, has_tilted = 0;
+    int two_rects[64];
+    for (int t = 0; t < c->n_trees; ++t) is_stump_based &= c->tree_n_nodes[t] == 1;
+    for (int i = 0; i < c->n_stages && i < 64; ++i) {
+        is_tree |= c->stage_next[i] != -1;
+        two_rects[i] = 1;
+        const int t0 = c->stage_first_tree[i], t1 = t0 + c->stage_n_trees[i];
+        (void)all_f64;
+        for (int t = t0; t < t1; ++t)
+            for (int l = 0; l < c->tree_n_nodes[t]; ++l) {
+                const int n = c->tree_first_node[t] + l;
+                const int32_t* r2 = c->node_rect + (n * 3 + 2) * 4;
+                /* :452-457: rect[2] counts unless |weight| < DBL_EPSILON or its width / height is 0 */
+                if (!(fabs((double)c->node_weight[n * 3 + 2]) < 2.220446049250313e-16 || r2[2] == 0 || r2[3] == 0))
+                    two_rects[i] = 0;
+                if (c->node_tilted && c->node_tilted[n]) has_tilted = 1;
+            }
+    }
+    if (has_tilted) {
+        tilted = (int32_t*)calloc((size_t)sw * (H + 3), sizeof(int32_t));
+        oc_integral_tilted(gray, W, H, stride, tilted);
+    }
     int found = 0, n_factors = 0, scale_index = 0;
     double factor;
     for (n_factors = 0, factor = 1; factor * c->win_w < W - 10 && factor * c->win_h < H - 10;
@@ -544,19 +672,29 @@ int oc_detect_opencvlike(const oc_cascade* c, const uint8_t* gray, int W, int H,
         const int q0 = ex * sw + ex, q1 = ex * sw + ex + ew, q2 = (ex + eh) * sw + ex, q3 = (ex + eh) * sw + ex + ew;
         for (int n = 0; n < c->n_nodes; ++n) {
             double sum0 = 0, area0 = 0;
-            int nr = 0;
-            while (nr < 3 && c->node_weight[n * 3 + nr] != 0) nr++;
+            /* rects 0 and 1 always count (their p0 is never null); rect 2 unless icvCreateHid... zeroed it (:452-455) */
+            const int32_t* r2 = c->node_rect + (n * 3 + 2) * 4;
+            const int nr = (fabs((double)c->node_weight[n * 3 + 2]) < 2.220446049250313e-16 || r2[2] == 0 || r2[3] == 0) ? 2 : 3;
             kn[n].nrect = nr;
+            kn[n].tilted = c->node_tilted ? c->node_tilted[n] != 0 : 0;
             kn[n].threshold = c->node_threshold[n];
+            const double correction_ratio = weight_scale * (!kn[n].tilted ? 1 : 0.5);   /* :731 */
             for (int k = 0; k < nr; ++k) {
                 const int32_t* r = c->node_rect + (n * 3 + k) * 4;
                 const int tx = cv_round(r[0] * factor), ty = cv_round(r[1] * factor);
                 const int tw = cv_round(r[2] * factor), th = cv_round(r[3] * factor);
-                kn[n].rect[k].p0 = ty * sw + tx;
-                kn[n].rect[k].p1 = ty * sw + tx + tw;
-                kn[n].rect[k].p2 = (ty + th) * sw + tx;
-                kn[n].rect[k].p3 = (ty + th) * sw + tx + tw;
-                kn[n].rect[k].weight = (float)(c->node_weight[n * 3 + k] * weight_scale);
+                if (!kn[n].tilted) {
+                    kn[n].rect[k].p0 = ty * sw + tx;
+                    kn[n].rect[k].p1 = ty * sw + tx + tw;
+                    kn[n].rect[k].p2 = (ty + th) * sw + tx;
+                    kn[n].rect[k].p3 = (ty + th) * sw + tx + tw;
+                } else {   /* :743-750 */
+                    kn[n].rect[k].p2 = (ty + tw) * sw + tx + tw;
+                    kn[n].rect[k].p3 = (ty + tw + th) * sw + tx + tw - th;
+                    kn[n].rect[k].p0 = ty * sw + tx;
+                    kn[n].rect[k].p1 = (ty + th) * sw + tx - th;
+                }
+                kn[n].rect[k].weight = (float)(c->node_weight[n * 3 + k] * correction_ratio);
                 if (k == 0) area0 = tw * th;
                 else sum0 += kn[n].rect[k].weight * tw * th;
             }
@@ -573,42 +711,77 @@ int oc_detect_opencvlike(const oc_cascade* c, const uint8_t* gray, int W, int H,
                     result = -1;
                 } else {
                     const int po = y * sw + x;
-                    double mean = (double)(sum[po + q0] - sum[po + q1] - sum[po + q2] + sum[po + q3]) * weight_scale;
+                    double mean = (double)(int)((uint32_t)sum[po + q0] - (uint32_t)sum[po + q1] - (uint32_t)sum[po + q2] +
+                                                (uint32_t)sum[po + q3]) * weight_scale;
                     double vnf = sqsum[po + q0] - sqsum[po + q1] - sqsum[po + q2] + sqsum[po + q3];
                     vnf = vnf * weight_scale - mean * mean;
                     vnf = vnf >= 0. ? sqrt(vnf) : 1.;
-                    int ptr = 0;
-                    result = 1;
-                    while (ptr != -1) {
-                        double stage_sum = 0.0;
-                        const int t0 = c->stage_first_tree[ptr], t1 = t0 + c->stage_n_trees[ptr];
-                        st->stage_entered[ptr]++;
-                        for (int t = t0; t < t1; ++t) {
-                            const int n0 = c->tree_first_node[t];
-                            const float* alpha = c->alpha + c->tree_first_alpha[t];
-                            int idx = 0;
-                            do {
-                                const cv_node* k = kn + n0 + idx;
-                                const double tt = k->threshold * vnf;
-                                double s = (double)(sum[po + k->rect[0].p0] - sum[po + k->rect[0].p1] - sum[po + k->rect[0].p2] +
-                                                    sum[po + k->rect[0].p3]) * k->rect[0].weight;
-                                s += (double)(sum[po + k->rect[1].p0] - sum[po + k->rect[1].p1] - sum[po + k->rect[1].p2] +
-                                              sum[po + k->rect[1].p3]) * k->rect[1].weight;
-                                if (k->nrect > 2)
-                                    s += (double)(sum[po + k->rect[2].p0] - sum[po + k->rect[2].p1] - sum[po + k->rect[2].p2] +
-                                                  sum[po + k->rect[2].p3]) * k->rect[2].weight;
-                                st->stump_evals++;
-                                idx = s < tt ? c->node_left[n0 + idx] : c->node_right[n0 + idx];
-                            } while (idx > 0);
-                            stage_sum += alpha[-idx];
+                    if (is_tree) {   /* :834-861: any reject returns 0 */
+                        int ptr = 0;
+                        result = 1;
+                        while (ptr != -1) {
+                            double stage_sum = 0.0;
+                            const int t0 = c->stage_first_tree[ptr], t1 = t0 + c->stage_n_trees[ptr];
+                            st->stage_entered[ptr]++;
+                            for (int t = t0; t < t1; ++t) {
+                                const int n0 = c->tree_first_node[t];
+                                const float* alpha = c->alpha + c->tree_first_alpha[t];
+                                int idx = 0;
+                                do {
+                                    const cv_node* k = kn + n0 + idx;
+                                    const double tt = k->threshold * vnf;
+                                    const double s = cv_node_sum_f32(sum, tilted, po, k);
+                                    st->stump_evals++;
+                                    idx = s < tt ? c->node_left[n0 + idx] : c->node_right[n0 + idx];
+                                } while (idx > 0);
+                                stage_sum += alpha[-idx];
+                            }
+                            if (stage_sum >= c->stage_threshold[ptr] - 0.0001f) {
+                                ptr = c->stage_child[ptr];
+                            } else {
+                                while (ptr != -1 && c->stage_next[ptr] == -1) ptr = c->stage_parent[ptr];
+                                if (ptr == -1) { result = 0; break; }
+                                ptr = c->stage_next[ptr];
+                            }
                         }
-                        if (stage_sum >= c->stage_threshold[ptr] - 0.0001f) {
-                            ptr = c->stage_child[ptr];
-                        } else {
-                            const int failed_at = ptr;
-                            while (ptr != -1 && c->stage_next[ptr] == -1) ptr = c->stage_parent[ptr];
-                            if (ptr == -1) { result = -failed_at; break; }   /* 0 when the first stage rejects */
-                            ptr = c->stage_next[ptr];
+                    } else {
+                        result = 1;
+                        for (int i = 0; i < c->n_stages; ++i) {
+                            double stage_sum = 0.0;
+                            const int t0 = c->stage_first_tree[i], t1 = t0 + c->stage_n_trees[i];
+                            st->stage_entered[i]++;
+                            for (int t = t0; t < t1; ++t) {
+                                const int n0 = c->tree_first_node[t];
+                                const float* alpha = c->alpha + c->tree_first_alpha[t];
+                                if (is_stump_based) {
+                                    const cv_node* k = kn + n0;
+                                    const double tt = k->threshold * vnf;
+                                    double s;
+                                    st->stump_evals++;
+                                    if (two_rects[i]) {   /* :872-888 */
+                                        const int32_t* img = k->tilted ? tilted : sum;
+                                        double rect0 = cv_calc_sum(img, po, &k->rect[0]);
+                                        rect0 *= k->rect[0].weight;
+                                        double rect1 = cv_calc_sum(img, po, &k->rect[1]);
+                                        rect1 *= k->rect[1].weight;
+                                        s = rect1 + rect0;
+                                    } else {              /* :907-911 */
+                                        s = cv_node_sum_f32(sum, tilted, po, k);
+                                    }
+                                    stage_sum += alpha[s >= tt];
+                                } else {                  /* :952-957 via icvEvalHidHaarClassifier */
+                                    int idx = 0;
+                                    do {
+                                        const cv_node* k = kn + n0 + idx;
+                                        const double tt = k->threshold * vnf;
+                                        const double s = cv_node_sum_f32(sum, tilted, po, k);
+                                        st->stump_evals++;
+                                        idx = s < tt ? c->node_left[n0 + idx] : c->node_right[n0 + idx];
+                                    } while (idx > 0);
+                                    stage_sum += alpha[-idx];
+                                }
+                            }
+                            if (stage_sum < c->stage_threshold[i] - 0.0001f) { result = -i; break; }
                         }
                     }
                 }
@@ -620,9 +793,23 @@ int oc_detect_opencvlike(const oc_cascade* c, const uint8_t* gray, int W, int H,
             }
         }
     }
-    free(kn); free(sum); free(sqsum);
+    free(kn); free(sum); free(sqsum); free(tilted);
+    g_all_f64 = 0;
     *n_total = found;
     return found < cap ? found : cap;
+}
+
+int oc_detect_opencvlike(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride,
+                         int min_w, int min_h, double scaleFactor,
+                         oc_rect* out, int cap, int* n_total, oc_stats* st) {
+    return detect_opencvlike_impl(c, gray, W, H, stride, min_w, min_h, scaleFactor, 0, out, cap, n_total, st);
+}
+
+/* NOT the reference's arithmetic (single-threaded test hook): every product in f64. */
+int oc_detect_opencvlike_all_f64(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride,
+                                 int min_w, int min_h, double scaleFactor,
+                                 oc_rect* out, int cap, int* n_total, oc_stats* st) {
+    return detect_opencvlike_impl(c, gray, W, H, stride, min_w, min_h, scaleFactor, 1, out, cap, n_total, st);
 }
 
 /* --------------------------------------------------------------- image ingest */

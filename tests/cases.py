@@ -47,3 +47,65 @@ def make_frame(generator: str, seed: int, h: int, w: int, oracle=None) -> np.nda
 
 def sha(a: np.ndarray) -> str:
     return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+# ----------------------------------------------------------------------------- OpenCV-profile arithmetic probes
+def crafted_stump_cascade(three_rects: bool, threshold: float):
+    """One stage, one stump, 20x20 window; leaves 0 / 1 and stage threshold 0.5: the window is a detection exactly
+    when the node sum is >= threshold * vnf.  The rectangles nearly cancel (like real Haar features), so the rounding
+    of each product shows in the sum."""
+    from oracle.oracle import CascadeArrays
+    c = CascadeArrays()
+    c.win_w = c.win_h = 20
+    c.name = "crafted"
+    c.stage_first_tree = np.array([0], np.int32)
+    c.stage_n_trees = np.array([1], np.int32)
+    c.stage_threshold = np.array([0.5], np.float32)
+    c.stage_parent = np.array([-1], np.int32)
+    c.stage_next = np.array([-1], np.int32)
+    c.stage_child = np.array([-1], np.int32)
+    c.tree_first_node = np.array([0], np.int32)
+    c.tree_n_nodes = np.array([1], np.int32)
+    c.tree_first_alpha = np.array([0], np.int32)
+    rects = [[2, 2, 16, 16], [2, 2, 8, 16], [10, 4, 4, 8] if three_rects else [0, 0, 0, 0]]
+    c.node_rect = np.array(rects, np.int32).reshape(-1)
+    c.node_weight = np.array([-1.0, 2.0, 0.5 if three_rects else 0.0], np.float32)
+    c.node_threshold = np.array([threshold], np.float32)
+    c.node_left = np.array([0], np.int32)
+    c.node_right = np.array([-1], np.int32)
+    c.node_tilted = np.array([0], np.int32)
+    c.alpha = np.array([0.0, 1.0], np.float32)
+    return c
+
+
+def single_window_frame(seed: int, size: int = 600):
+    """(bright noisy frame, factor): at the largest factor of cvHaarDetectObjects' loop for a 20x20 cascade the frame
+    holds exactly one window, at (0, 0), whose rectangle sums are far above 2^24."""
+    rng = np.random.default_rng(seed)
+    img = (180 + rng.integers(0, 76, (size, size))).astype(np.uint8)
+    factor, n = 1.0, 0
+    while factor * 20 < size - 10:
+        last = factor
+        factor *= 1.1
+    return img, last
+
+
+def cascade_to_product(c):
+    """oracle CascadeArrays -> product Cascade through vj_cascade_from_arrays."""
+    from clfacedetection_amd import Cascade
+    from clfacedetection_amd.api import NODE_DTYPE, STAGE_DTYPE, TREE_DTYPE
+    st = np.zeros(c.n_stages, STAGE_DTYPE)
+    st["first_tree"], st["n_trees"], st["threshold"] = c.stage_first_tree, c.stage_n_trees, c.stage_threshold
+    st["parent"], st["next"], st["child"] = c.stage_parent, c.stage_next, c.stage_child
+    tr = np.zeros(c.n_trees, TREE_DTYPE)
+    tr["first_node"], tr["n_nodes"], tr["first_alpha"] = c.tree_first_node, c.tree_n_nodes, c.tree_first_alpha
+    nd = np.zeros(c.n_nodes, NODE_DTYPE)
+    r = c.node_rect.reshape(-1, 3, 4)
+    w = c.node_weight.reshape(-1, 3)
+    for k, f in enumerate(("x", "y", "w", "h")):
+        nd["rect"][f] = r[:, :, k]
+    nd["rect"]["weight"] = w
+    nd["n_rects"] = (w != 0).sum(1)
+    nd["tilted"] = c.node_tilted if len(c.node_tilted) == c.n_nodes else 0
+    nd["threshold"], nd["left"], nd["right"] = c.node_threshold, c.node_left, c.node_right
+    return Cascade.from_arrays(c.win_w, c.win_h, st, tr, nd, c.alpha)

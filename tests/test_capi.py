@@ -72,10 +72,43 @@ def test_argument_errors(lib):
     assert lib.vj_strerror(0) == b"ok" and lib.vj_strerror(99) == b"unknown error"
 
 
-def test_cpu_variants_are_refused():
+def test_cpu_variants_never_compute_on_the_cpu():
+    """use_opencl=False picks the WINDOW SET of the reference's CPU loops (skip modes), still on the device; the block
+    variant and clifIntegral's CPU branch (cvIntegral) are refused.  Nothing computes without an environment."""
     import numpy as np
-    from clfacedetection_amd import clodDetectObjects, clifIntegral
+    from clfacedetection_amd import CLOD_BLOCK_IMPLEMENTATION, clodDetectObjects, clifIntegral
     with pytest.raises(VjError):
+        clodDetectObjects(np.zeros((40, 40), np.uint8), None, None, flags=CLOD_BLOCK_IMPLEMENTATION, use_opencl=False)
+    with pytest.raises(AttributeError):   # no environment -> nothing to run on: there is no host evaluator to fall back to
         clodDetectObjects(np.zeros((40, 40), np.uint8), None, None, use_opencl=False)
     with pytest.raises(VjError):
         clifIntegral(np.zeros((4, 4), np.uint8), None, use_opencl=False)
+
+
+def test_cascade_from_arrays_round_trip_and_validation(lib):
+    """vj_cascade_from_arrays: what a cvLoad-ed CvHaarClassifierCascade converts to; equals the file-loaded cascade,
+    derives `child`, and rejects broken links."""
+    import numpy as np
+    from clfacedetection_amd import Cascade
+    for name in ("frontalface_alt", "frontalface_alt2", "frontalface_alt_tree"):
+        c = Cascade.load(name)
+        st = c.stages.copy()
+        st["child"] = -1                                   # as a caller that only has parent / next would pass them
+        c2 = Cascade.from_arrays(c.info.win_w, c.info.win_h, st, c.trees, c.nodes, c.alpha)
+        assert np.array_equal(c2.stages, c.stages) and np.array_equal(c2.trees, c.trees)
+        assert c2.nodes.tobytes() == c.nodes.tobytes() and c2.alpha.tobytes() == c.alpha.tobytes()
+        assert c2.count_windows(1920, 1080) == c.count_windows(1920, 1080)
+    c = Cascade.load("frontalface_alt")
+    bad = c.trees.copy()
+    bad["first_node"][5] = c.info.n_nodes                  # out of range
+    with pytest.raises(VjError):
+        Cascade.from_arrays(20, 20, c.stages, bad, c.nodes, c.alpha)
+    badn = c.nodes.copy()
+    badn["left"][0] = 3                                    # a stump pointing at a node that does not exist
+    with pytest.raises(VjError):
+        Cascade.from_arrays(20, 20, c.stages, c.trees, badn, c.alpha)
+    bads = c.stages.copy()
+    bads["parent"][3] = 7                                  # a parent that follows its child
+    with pytest.raises(VjError):
+        Cascade.from_arrays(20, 20, bads, c.trees, c.nodes, c.alpha)
+    assert lib.vj_cascade_from_arrays(20, 20, None, 0, None, 0, None, 0, None, 0, None) == 1

@@ -12,6 +12,7 @@ from oracle.oracle import load_vjc, parse_xml
 
 REF = "/root/reference/CLFaceDetection"
 NAMES = ["frontalface_default", "frontalface_alt", "frontalface_alt2", "frontalface_alt_tree", "eye"]
+TILTED = ["fullbody", "eye_tree_eyeglasses"]   # shipped for the OpenCV profile's tilted-feature tests
 # win, stages, trees, nodes, maxT, maxN, tilted, 3-rect
 TABLE = {
     "frontalface_default": (24, 25, 2913, 2913, 211, 1, 0, 557),
@@ -98,7 +99,7 @@ def test_xml_loader_matches_oracle_parser(tmp_path, xml):
 
 
 @pytest.mark.skipif(not os.path.isdir(REF), reason="reference tree not present")
-@pytest.mark.parametrize("name", NAMES)
+@pytest.mark.parametrize("name", NAMES + TILTED)
 def test_shipped_vjc_is_current(name):
     a = parse_xml(os.path.join(REF, f"haarcascade_{name}.xml"))
     assert a.same_as(load_vjc(os.path.join(DATA_DIR, f"haarcascade_{name}.vjc"))) == []

@@ -65,10 +65,73 @@ def test_flat_extreme_and_skip_rule_images(env, oracle, cascades):
     assert r.windows < sum((700 - 10) // 2 * ((240 - 10) // 2) for _ in range(1)) * 40   # sanity: a bounded count
 
 
-def test_refuses_stage_trees(env, cascades):
-    c, _ = cascades("frontalface_alt_tree")
-    with pytest.raises(Exception):
-        env.detect_opencv(c, np.zeros((200, 200), np.uint8))
+@pytest.mark.parametrize("kind,seed,h,w", [("noise", 71, 240, 320), ("blocks", 72, 300, 400), ("smooth", 73, 360, 500)])
+def test_stage_tree_cascade(env, oracle, cascades, kind, seed, h, w):
+    """frontalface_alt_tree: cvRunHaarClassifierCascadeSum's is_tree walk (tempcv.cpp:834-861) returns 0 on ANY reject, so
+    the invoker skips the next window after every rejected one (:1163), not only after a stage-0 reject."""
+    c, a = cascades("frontalface_alt_tree")
+    img = make_frame(kind, seed, h, w, oracle)
+    r = env.detect_opencv(c, img, flags=VJ_FLAG_COUNTERS)
+    ro, st = oracle.detect_opencvlike(a, img)
+    assert sorted(rows(r.rects)) == sorted(rows(ro))
+    assert r.windows == st["windows"] and r.stage_entered == st["stage_entered"]
+
+
+@pytest.mark.parametrize("casc,kind,seed,h,w", [
+    ("fullbody", "noise", 81, 240, 320),                 # 14x28 stumps, 201 tilted features
+    ("fullbody", "blocks", 82, 400, 300),
+    ("eye_tree_eyeglasses", "noise", 83, 240, 320),      # trees of up to 3 nodes, 577 tilted features
+    ("eye_tree_eyeglasses", "smooth", 84, 300, 420),
+])
+def test_tilted_features(env, oracle, cascades, casc, kind, seed, h, w):
+    """Tilted rectangles read four corners of the tilted integral image (tempcv.cpp:743-750), weight correction 0.5 (:731)."""
+    c, a = cascades(casc)
+    assert c.info.n_tilted > 0
+    img = make_frame(kind, seed, h, w, oracle)
+    r = env.detect_opencv(c, img, flags=VJ_FLAG_COUNTERS)
+    ro, st = oracle.detect_opencvlike(a, img)
+    assert sorted(rows(r.rects)) == sorted(rows(ro))
+    assert r.windows == st["windows"] and r.stage_entered == st["stage_entered"]
+
+
+def test_tilted_integral_and_gray_image(env, oracle):
+    """vj_integral_tilted (cvIntegral's tilted output) and vj_grayscale (clifGrayscale) against the oracle, odd sizes,
+    BGR input and the 32-bit wrap-around included."""
+    rng = np.random.default_rng(5)
+    for (h, w) in [(1, 1), (3, 5), (64, 300), (251, 333), (480, 640), (1080, 1920)]:
+        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+        assert np.array_equal(env.integral_tilted(img), oracle.integral_tilted(img)), (h, w)
+        assert np.array_equal(env.grayscale(img), img)
+    white = np.full((3000, 3000), 255, np.uint8)              # tilted sums pass 2^32
+    assert np.array_equal(env.integral_tilted(white), oracle.integral_tilted(white))
+    bgr = rng.integers(0, 256, (120, 200, 3), dtype=np.uint8)
+    g = oracle.bgr2gray(bgr)
+    assert np.array_equal(env.grayscale(bgr), g)
+    assert np.array_equal(env.integral_tilted(bgr), oracle.integral_tilted(g))
+    bgra = rng.integers(0, 256, (77, 131, 4), dtype=np.uint8)
+    assert np.array_equal(env.grayscale(bgra[20:60, 10:100]), oracle.bgr2gray(np.ascontiguousarray(bgra[20:60, 10:100])))
+
+
+@pytest.mark.parametrize("three_rects", [True, False])
+def test_node_products_follow_the_scalar_branch(env, oracle, three_rects):
+    """The window of tests/test_oracle_cv.py whose verdict depends on HOW the rectangle sums are multiplied: binary32
+    products (int * float, tempcv.cpp:907-911) when the stage has a three-rectangle node, f64 products (:872-888) in a
+    two_rects stage.  The device must land on the reference's side of the threshold in both."""
+    from cases import cascade_to_product, crafted_stump_cascade, single_window_frame
+    from test_oracle_cv import numpy_single_window
+    img, factor = single_window_frame(seed=5)
+    c0 = crafted_stump_cascade(three_rects, threshold=0.0)
+    s32 = numpy_single_window(c0, img, factor, False)[0]
+    s64 = numpy_single_window(c0, img, factor, True)[0]
+    vnf = numpy_single_window(crafted_stump_cascade(three_rects, threshold=1.0), img, factor, False)[1]
+    a = crafted_stump_cascade(three_rects, threshold=float(np.float32((s32 + s64) / 2 / vnf)))
+    win = int(np.rint(a.win_w * factor))
+    ro, _ = oracle.detect_opencvlike(a, img, min_size=(win, win))
+    r = env.detect_opencv(cascade_to_product(a), img, min_size=(win, win), flags=VJ_FLAG_COUNTERS)
+    assert r.windows == 1 and len(r.rects) == len(ro)
+    literal = numpy_single_window(a, img, factor, f64_products=not three_rects)[2]
+    other = numpy_single_window(a, img, factor, f64_products=three_rects)[2]
+    assert literal != other and (len(r.rects) == 1) == literal
 
 
 def test_color_frames_subbatches_and_many_detections(env, oracle, cascades):
@@ -92,12 +155,13 @@ def test_color_frames_subbatches_and_many_detections(env, oracle, cascades):
     assert sorted(rows(base.rects[base.rects["frame"] == 0])) == sorted(rows(ro))
 
 
-@pytest.mark.parametrize("seed", range(12))
+@pytest.mark.parametrize("seed", range(14))
 def test_randomized_parity(env, oracle, cascades, seed):
     """Random sizes, cascades, min sizes and scale factors: rectangles, visited windows and per-stage counts equal the
     oracle's restatement."""
     rng = np.random.default_rng(2000 + seed)
-    casc = ["frontalface_alt", "frontalface_default", "frontalface_alt2", "eye"][seed % 4]
+    casc = ["frontalface_alt", "frontalface_default", "frontalface_alt2", "eye", "frontalface_alt_tree", "fullbody",
+            "eye_tree_eyeglasses"][seed % 7]
     c, a = cascades(casc)
     w = int(rng.integers(c.info.win_w + 12, 800))
     h = int(rng.integers(c.info.win_h + 12, 560))
