@@ -2,7 +2,7 @@
 """Headline benchmark of the MI355X-native Viola–Jones detect path.
 
 Metric (BASELINE.json): candidate windows/sec (+ Mpix/s) on 1080p frames with
-haarcascade_frontalface_alt, 1/2/4/8 GPUs.  A "step" is one pass of the whole hot path
+haarcascade_frontalface_alt, 1/2/4/8 GPUs — BASELINE config 3.  A "step" is one pass of the whole hot path
 (integral + squared-integral kernels, all cascade passes, detection read-back and — for
 N > 1 — the all-gather of detection rectangles) over one batch of synthetic frames that
 is already resident in HBM.  Per-GPU work is fixed (weak scaling): every rank owns a
@@ -13,15 +13,29 @@ batch of --frames 1080p frames; there is no data-path collective besides that ga
         --master-port P bench.py --gpus N --steps K --warmup W
 
 Rank 0 prints ONE JSON line.  `value` is whole-job windows/s over the K timed steps
-(max over ranks of the wall time, barrier + synchronize on both sides).  `roofline`
-is for the dominant kernel, the first cascade pass, from HIP events recorded inside the
-library on the stream the kernels run on.  `cpu_baseline` is the CPU oracle
-(oracle/vj_oracle.c, a single-threaded restatement of the reference's clod path) timed
-on a bounded sample of the same frames, and doubles as a parity check of that sample.
+(max over ranks of the wall time, barrier + synchronize on both sides).
+
+`roofline` is for the dominant kernel — the kernel group with the most time per step — against the ceiling that
+binds THAT kernel: the LDS-tile kernel gathers from LDS (`bound: "lds"`, peak = the guide's
+aggregate ds_read_b32 rate), the global-gather passes from the L2 (`"l2"`), the integral kernels stream HBM
+(`"hbm"`).  `achieved` = algorithmic bytes per launch (48 B per window + 16 B per evaluated rectangle,
+from a counted run's PER-LAUNCH counters) over the launch's HIP-event time, measured live on the stream the kernel
+runs on.  `kernels` carries the same figures for every group.  `traffic` (HBM bytes per launch from rocprofv3 PMC
+passes) is only reported when profiles/pmc_dominant.json was collected from the kernel sources of this very build.
+
+`cpu_baseline` is the CPU oracle (oracle/vj_oracle.c, a single-threaded restatement of the reference's clod path)
+timed on a bounded sample of the same frames; the sample doubles as a parity check of the TIMED (uncounted) step.
+
+`extra` (N = 1 only; --extras "" turns it off) measures the other BASELINE configs in the same run:
+  config2  one 1080p frame, host buffer in -> rectangles out: p50 / p90 latency over >= 50 calls
+  config3_host_frames  config 3 with the frames in (page-locked) HOST memory: double-buffered vj_stream, H2D included
+  config4  one 4096x4096 frame, frontalface_alt_tree
+  config5  256 x 720p, frontalface_alt2 -> haarcascade_eye on every face candidate, hand-off on the device
 """
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -32,7 +46,25 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; L2 ~34.5 TB/s aggregate; LDS ~75 TB/s aggregate for ds_read_b32 gathers
+# (128 B/clk/CU x 256 CUs at ~2.4 GHz; b64 / b128 reads reach ~150 TB/s but a dword gather cannot use them)
+PEAK_GBPS = {"hbm": 8000.0, "l2": 34500.0, "lds": 75000.0}
+KERNEL_OF = {"tile": ("vj::cascade_tile_pass<false, false, true>", "lds"),
+             "block": ("vj::cascade_tile_pass<false, false, false>", "l2"),
+             "grid": ("vj::cascade_pass<true, false, *, false, false>", "l2"),
+             "queue": ("vj::cascade_pass<false, false, *, false, false>", "l2")}
+
+
+def kernel_source_hash() -> str:
+    h = hashlib.sha256()
+    for f in ("vj_kernels.hip", "vj_device.hpp", "vj_devutil.hpp"):
+        h.update(open(os.path.join(ROOT, "clfacedetection_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def rows_of(rects, frame=None):
+    r = rects if frame is None else rects[rects["frame"] == frame]
+    return [tuple(int(x[k]) for k in ("scale_idx", "x", "y", "w", "h")) for x in r]
 
 
 def main() -> int:
@@ -45,9 +77,12 @@ def main() -> int:
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cascade", default="frontalface_alt")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the batch timed on the CPU oracle (0 = skip)")
+    ap.add_argument("--extras", "--config", default="2,3h,4,5", help="other BASELINE configs measured into `extra` "
+                    "(2, 3h = config 3 from host frames, 4, 5; \"\" = none)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
+    ap.add_argument("--no-pipeline", action="store_true", help="time blocking vj_detect calls instead of a two-deep vj_stream")
     ap.add_argument("--pass-split", default=None)
     ap.add_argument("--blocks-per-cu", type=int, default=None)
     args = ap.parse_args()
@@ -110,11 +145,39 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one counted run: algorithmic bytes + the detections used for the parity sample
+    # one counted run: algorithmic bytes per launch (the counted kernel variants are slower and never timed)
     counted, _ = step(default_params(flags=VJ_FLAG_COUNTERS))
     p = default_params()
-    for _ in range(args.warmup):
-        step(p)
+    # The timed steps go through a vj_stream (two batches in flight): step k's read-back, decode and sort on the host
+    # overlap step k+1's kernels.  Every step still does everything — integral images, all cascade passes, read-back,
+    # sorted rectangles (and the all-gather for N > 1) — and all of it completes inside the timed bracket; the frames
+    # are device-resident, so the stream uses them in place (no copy).  --no-pipeline times blocking calls instead.
+    stream = None if args.no_pipeline else env.stream(casc, W, H, B, p)
+
+    def finish(r):
+        rects = r.rects
+        if world > 1:
+            rects = rects.copy()
+            rects["frame"] += rank * B
+            rects = multigpu.allgather_rects(rects, device=coll_dev)
+        return r, rects
+
+    def run_steps(n):
+        """n whole steps; yields (result, gathered rects) of each."""
+        if stream is None:
+            for _ in range(n):
+                yield step(p)
+            return
+        if n == 0:
+            return
+        stream.submit(dframes)
+        for _ in range(n - 1):
+            stream.submit(dframes)
+            yield finish(stream.collect())
+        yield finish(stream.collect())
+
+    for _ in run_steps(args.warmup):
+        pass
     barrier()
     t0 = time.perf_counter()
     integral_ms = cascade_ms = 0.0
@@ -122,8 +185,8 @@ def main() -> int:
     launch_ms = None
     launches = None
     n_det_total = 0
-    for _ in range(args.steps):
-        r, rects = step(p)
+    timed_rects = None
+    for r, rects in run_steps(args.steps):
         integral_ms += r.integral_ms
         cascade_ms += r.cascade_ms
         pm = [x[2] for x in r.passes]
@@ -132,6 +195,7 @@ def main() -> int:
         launch_ms = lm if launch_ms is None else [a + b for a, b in zip(launch_ms, lm)]
         launches = r.launches
         n_det_total = len(rects)
+        timed_rects = r.rects
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -146,39 +210,20 @@ def main() -> int:
     out = None
     if rank == 0:
         K = max(args.steps, 1)
-        # ---- roofline of the dominant kernel.  Launches are grouped by kernel (the names
-        # rocprofv3 --kernel-trace --stats reports); the group with the most time is the
-        # dominant kernel.  Algorithmic bytes: 48 B per window for the
-        # variance gathers + 16 B per evaluated rectangle, from counted runs restricted to
-        # the scales each launch covers; time = HIP events recorded inside the library on
-        # the stream the kernels run on, averaged over the timed steps.
+        # ---- per-kernel rooflines.  Launches are grouped by kernel (the names rocprofv3 --kernel-trace --stats
+        # reports); algorithmic bytes come from the counted run's PER-LAUNCH counters, time from the
+        # HIP events the library records around every launch on the stream it runs on, averaged over the timed steps.
         nodes, trees, stages = casc.nodes, casc.trees, casc.stages
         rects_per_stage = []
         for st in stages:
             tr = trees[st["first_tree"]:st["first_tree"] + st["n_trees"]]
             rects_per_stage.append(int(sum(int(nodes["n_rects"][t["first_node"]:t["first_node"] + t["n_nodes"]].sum())
                                            for t in tr)))
-        kname = {"tile": "vj::cascade_tile_pass<false, false, true>", "block": "vj::cascade_tile_pass<false, false, false>",
-                 "grid": "vj::cascade_pass<true, false, *, false, false>",
-                 "queue": "vj::cascade_pass<false, false, *, false, false>"}
         groups = {}
         for l, ms in zip(launches, launch_ms):
-            g = groups.setdefault(l["kind"], {"ms": 0.0, "n": 0, "launches": []})
+            g = groups.setdefault(l["kind"], {"ms": 0.0, "n": 0})
             g["ms"] += ms / K
             g["n"] += 1
-            g["launches"].append(l)
-        dom_kind = max(groups, key=lambda k: groups[k]["ms"])
-        dom = groups[dom_kind]
-        # algorithmic bytes of the dominant kernel's launches from the counted run's PER-LAUNCH counters
-        alg = 0
-        for l in counted.launches:
-            if l["kind"] != dom_kind:
-                continue
-            if l["kind"] != "queue":
-                alg += 48 * l["stage_entered"][0]
-            alg += 16 * sum(n * rects_per_stage[st] for st, n in enumerate(l["stage_entered"]))
-        # the same figure for every kernel group (the chains overlap, so each kernel's own time is the time it was
-        # resident, not a share of the step)
         per_kernel = {}
         for kind, grp in groups.items():
             b = 0
@@ -188,31 +233,47 @@ def main() -> int:
                 if kind != "queue":
                     b += 48 * l["stage_entered"][0]
                 b += 16 * sum(n * rects_per_stage[st] for st, n in enumerate(l["stage_entered"]))
-            per_kernel[kind] = {"kernel": kname[kind], "launches_per_step": grp["n"], "ms_per_step": round(grp["ms"], 3),
-                                "algorithmic_GB_per_step": round(b / 1e9, 2),
-                                "achieved_GBps": round(b / (grp["ms"] * 1e-3) / 1e9, 1) if grp["ms"] > 0 else None}
-        achieved = alg / (dom["ms"] * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")   # from rocprofv3 --pmc passes (tools/pmc_traffic.py)
+            name, bound = KERNEL_OF[kind]
+            ach = b / (grp["ms"] * 1e-3) / 1e9 if grp["ms"] > 0 else 0.0
+            per_kernel[kind] = {"kernel": name, "bound": bound, "launches_per_step": grp["n"], "ms_per_step": round(grp["ms"], 3),
+                                "avg_launch_ms": round(grp["ms"] / grp["n"], 4),
+                                "algorithmic_bytes_per_launch": int(b // grp["n"]),
+                                "achieved": round(ach, 1), "peak": PEAK_GBPS[bound], "unit": "GB/s",
+                                "frac": round(ach / PEAK_GBPS[bound], 4)}
+        int_ach = 13 * W * H * B / (integral_ms / K * 1e-3) / 1e9
+        per_kernel["integral"] = {"kernel": "vj::band_colsum + vj::band_scan + vj::band_rows", "bound": "hbm", "launches_per_step": 3,
+                                  "ms_per_step": round(integral_ms / K, 4), "algorithmic_bytes_per_launch": 13 * W * H * B,
+                                  "achieved": round(int_ach, 1), "peak": PEAK_GBPS["hbm"], "unit": "GB/s",
+                                  "frac": round(int_ach / PEAK_GBPS["hbm"], 4),
+                                  "note": "1 B read + 12 B written per pixel over the three launches together"}
+        dom_kind = max(groups, key=lambda k: groups[k]["ms"])
+        dom = per_kernel[dom_kind]
+        # measured HBM traffic and SQ counters of the dominant kernel: only from a profile of THIS build's kernels
+        traffic, pmc_note, pmc_extra = None, "no rocprofv3 PMC profile of this build's kernels is committed", {}
+        pmc = os.path.join(ROOT, "profiles", "pmc_dominant.json")
         if os.path.exists(pmc):
             try:
                 j = json.load(open(pmc))
-                if j.get("kernel_kind") == dom_kind:
+                if j.get("kernel_kind") == dom_kind and j.get("kernel_source_hash") == kernel_source_hash():
                     traffic = j.get("hbm_bytes_per_launch")
+                    pmc_note = f"profiles/pmc_dominant.json (from {j.get('source')}, kernel sources {j.get('kernel_source_hash')})"
+                    pmc_extra = {k: j[k] for k in ("lds_bank_conflict_share", "valu_busy", "lds_busy", "wave_wait_share") if k in j}
+                else:
+                    pmc_note = "profiles/pmc_dominant.json was collected from other kernel sources: not reported"
             except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": kname[dom_kind], "launches_per_step": dom["n"],
-                    "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
-                    "algorithmic_bytes_per_launch": int(alg // dom["n"]),
-                    "avg_launch_ms": round(dom["ms"] / dom["n"], 4),
-                    "note": "gathers are served from LDS tiles / L2, not HBM: see DESIGN.md for the LDS and "
-                            "texture-address ceilings that actually bound these kernels"}
+                pass
+        roofline = {"bound": dom["bound"], "kernel": dom["kernel"], "launches_per_step": dom["launches_per_step"],
+                    "achieved": dom["achieved"], "peak": dom["peak"], "unit": "GB/s", "frac": dom["frac"],
+                    "traffic": traffic, "traffic_source": pmc_note,
+                    "algorithmic_bytes_per_launch": dom["algorithmic_bytes_per_launch"], "avg_launch_ms": dom["avg_launch_ms"],
+                    "hbm_frac_of_traffic": round(traffic / (dom["avg_launch_ms"] * 1e-3) / 1e9 / PEAK_GBPS["hbm"], 4) if traffic else None,
+                    **pmc_extra,
+                    "note": "the dominant kernel gathers from image tiles staged in LDS: its ceiling is the LDS gather rate "
+                            "(ds_read_b32), not HBM; measured HBM traffic is `traffic`"}
 
-        # ---- CPU baseline: the oracle, 1 thread, on the first --cpu-frames frames (also a parity check)
-        cpu = None
-        cpu_mt = None
-        cpu_cv = None
+        # ---- CPU baseline: the oracle, 1 thread, on the first --cpu-frames frames; the same sample checks the
+        # rectangles of the TIMED step (uncounted kernel variants) and of the counted run
+        cpu = cpu_mt = cpu_cv = None
         parity = None
         if world == 1 and args.cpu_frames > 0:
             from oracle.oracle import Oracle, load_vjc
@@ -224,11 +285,10 @@ def main() -> int:
             parity = True
             for f in range(n_cpu):
                 ro, _ = o.detect(a, frames_h[f])
-                mine = counted.rects[counted.rects["frame"] == f]
-                same = len(ro) == len(mine) and all(np.array_equal(ro[k], mine[k])
-                                                    for k in ("scale_idx", "x", "y", "w", "h"))
-                parity = parity and bool(same)
+                want = rows_of(ro)
+                parity = parity and rows_of(timed_rects, f) == want and rows_of(counted.rects, f) == want
             cpu_s = time.perf_counter() - t1
+            parity = parity and bool(np.array_equal(timed_rects, counted.rects))   # every frame: timed == counted variants
             cpu = {"value": round(windows_per_frame * n_cpu / cpu_s, 1), "unit": "windows/s", "cores": 1,
                    "kind": "port", "sample": f"first {n_cpu} of the {B} frames, {cpu_s:.1f} s, oracle/vj_oracle.c "
                    f"(gcc -O2 -ffp-contract=off, integral + all scales + all stages)"}
@@ -241,9 +301,8 @@ def main() -> int:
             mt_s = time.perf_counter() - t2
             cpu_mt = {"value": round(windows_per_frame * n_thr / mt_s, 1), "unit": "windows/s", "cores": n_thr,
                       "kind": "port", "sample": f"{n_thr} frames, one per thread, {mt_s:.1f} s"}
-            # north_star's other CPU leg: the OpenCV-style scale-cascade path as tempcv.cpp keeps it (f64 sums,
-            # ystep = max(2, factor), stage-0 skip).  It visits fewer windows than clod by design, so its honest
-            # unit is frames/s; compare with this line's "frames_per_s".
+            # north_star's other CPU leg: the OpenCV-style scale-cascade path as tempcv.cpp keeps it.  It visits fewer
+            # windows than clod by design, so its honest unit is frames/s; compare with this line's "frames_per_s".
             t3 = time.perf_counter()
             vis = 0
             for f in range(n_cpu):
@@ -259,9 +318,9 @@ def main() -> int:
                       "windows_visited_per_frame": vis // n_cpu,
                       "sample": f"first {n_cpu} frames, {cv_s:.1f} s, oc_detect_opencvlike (restates tempcv.cpp "
                                 f"cvHaarDetectObjects; unpinned, timing only)"}
-        # the OpenCV arithmetic profile on the same frames (vj_detect_opencv: f64 sums, skip rule; one global-gather
-        # kernel, not tuned): what a cvHaarDetectObjects user gets, next to cpu_baseline_opencvlike
+        # the OpenCV arithmetic profile on the same frames (vj_detect_opencv): what a cvHaarDetectObjects user gets
         cv_profile = None
+        extra = {}
         if world == 1:
             env.detect_opencv(casc, dframes)
             t5 = time.perf_counter()
@@ -269,15 +328,17 @@ def main() -> int:
             cv_s = time.perf_counter() - t5
             cv_profile = {"frames_per_s": round(B / cv_s, 1), "ms_per_step": round(cv_s * 1e3, 2),
                           "windows_visited_per_frame": rcv.windows // B, "detections": len(rcv.rects), "dtype": "f64"}
+            extra = run_extras(env, casc, frames_h, [x.strip() for x in args.extras.split(",") if x.strip()], torch)
         out = {
             "metric": "candidate windows/sec, 1080p, haarcascade_frontalface_alt",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "u32 gathers + f32 stage sums", "data": "synthetic",
-            "config": {"workload": f"{B}x{W}x{H} 8-bit frames per GPU per step (noise/smooth/blocks mix), "
+            "config": {"workload": f"BASELINE config 3: {B}x{W}x{H} 8-bit frames per GPU per step (noise/smooth/blocks mix), "
                                    f"haarcascade_{args.cascade}, scaleFactor 1.1f, raw candidates, frames resident in HBM",
                        "frames_per_gpu": B, "windows_per_frame": windows_per_frame,
-                       "pass_split": [x[0] for x in counted.passes], "device": env.device_name},
+                       "pass_split": [x[0] for x in counted.passes], "device": env.device_name,
+                       "pipeline": "blocking vj_detect calls" if args.no_pipeline else "vj_stream, two batches in flight"},
             "mpix_per_s": round(W * H * B * world * args.steps / elapsed / 1e6, 1),
             "frames_per_s": round(B * world * args.steps / elapsed, 1),
             "detections_last_step": int(n_det_total),
@@ -286,15 +347,13 @@ def main() -> int:
                                    "launches": [{"kind": l["kind"], "lds_class": l["lds_class"],
                                                  "stages": [l["stage_begin"], l["stage_end"]], "n_scales": len(l["scales"]),
                                                  "ms": round(ms / K, 4)} for l, ms in zip(launches, launch_ms)]},
-            # the one genuinely HBM-bound kernel group: 1 B read + 12 B written per pixel
-            "integral_roofline": {"bound": "hbm", "achieved": round(13 * W * H * B / (integral_ms / K * 1e-3) / 1e9, 1),
-                                  "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                  "frac": round(13 * W * H * B / (integral_ms / K * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)},
             "stump_evals_per_window": round(counted.stump_evals / max(counted.windows, 1), 3),
-            "cascade_algorithmic_GBps": round(counted.gather_bytes / (cascade_ms / K * 1e-3) / 1e9, 2),
+            "stump_evals_per_s": round(counted.stump_evals / (ms_per_step * 1e-3), 1),
             "roofline": roofline, "kernels": per_kernel, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
-            "cpu_baseline_opencvlike": cpu_cv, "opencv_profile": cv_profile, "parity_sample_ok": parity,
+            "cpu_baseline_opencvlike": cpu_cv, "opencv_profile": cv_profile, "parity_sample_ok": parity, "extra": extra,
         }
+    if stream is not None:
+        stream.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -304,6 +363,97 @@ def main() -> int:
             print("bench.py: PARITY FAILURE on the CPU sample", file=sys.stderr)
             return 4
     return 0
+
+
+def run_extras(env, casc_alt, frames_h, which, torch) -> dict:
+    """The other BASELINE configs, bounded to a few seconds each.  Synthetic frames; every figure is wall-clock around
+    whole library calls (host in -> rectangles out), so launch overhead, read-back and the host-side sort are included."""
+    from clfacedetection_amd import Cascade, DeviceFrames, default_params, synth
+    extra = {}
+    pct = lambda v, q: float(np.percentile(np.asarray(v), q))
+    if "2" in which:
+        # config 2: one 1080p frame per call, the reference's per-frame pattern (main.cpp:159-184): host buffer in, rects out
+        f = frames_h[0]
+        ws = casc_alt.count_windows(f.shape[1], f.shape[0])
+        for _ in range(5):
+            env.detect(casc_alt, f)
+        lat, kern, integ = [], [], []
+        for i in range(60):
+            img = frames_h[i % len(frames_h)]
+            t = time.perf_counter()
+            r = env.detect(casc_alt, img)
+            lat.append((time.perf_counter() - t) * 1e3)
+            kern.append(r.total_ms)
+            integ.append(r.integral_ms)
+        extra["config2"] = {"workload": "1x1920x1080, frontalface_alt, host frame in -> rects out, 60 calls",
+                            "latency_ms_p50": round(pct(lat, 50), 3), "latency_ms_p90": round(pct(lat, 90), 3),
+                            "kernels_ms_p50": round(pct(kern, 50), 3), "integral_ms_p50": round(pct(integ, 50), 4),
+                            "windows_per_s_at_p50": round(ws / (pct(lat, 50) * 1e-3), 1)}
+    if "3h" in which:
+        # config 3 with the frames in page-locked HOST memory: vj_stream uploads batch k+1 while batch k computes
+        B, H, W = frames_h.shape
+        st = env.stream(casc_alt, W, H, B)
+        bufs = [env.host_alloc((B, H, W)) for _ in range(2)]
+        try:
+            for b in bufs:
+                b[...] = frames_h
+            st.submit(bufs[0])
+            n = 8
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for k in range(1, n + 1):
+                st.submit(bufs[k % 2])
+                st.collect()
+            dt = (time.perf_counter() - t) / n
+            st.collect()
+            extra["config3_host_frames"] = {"workload": f"{B}x{W}x{H} frames in page-locked host memory, double-buffered vj_stream "
+                                                        "(H2D of batch k+1 overlaps the kernels of batch k)",
+                                            "ms_per_step": round(dt * 1e3, 3),
+                                            "windows_per_s": round(casc_alt.count_windows(W, H) * B / dt, 1)}
+        finally:
+            st.close()
+            for b in bufs:
+                env.host_free(b)
+    if "4" in which:
+        c = Cascade.load("frontalface_alt_tree")
+        f = synth.batch(1, 4096, 4096, seed0=4001, kinds=("blocks",))
+        d = torch.from_numpy(f).cuda()
+        df = DeviceFrames.from_torch(d)
+        ws = c.count_windows(4096, 4096)
+        for _ in range(2):
+            env.detect(c, df)
+        lat = []
+        for _ in range(8):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = env.detect(c, df)
+            lat.append((time.perf_counter() - t) * 1e3)
+        extra["config4"] = {"workload": "1x4096x4096 (blocks), frontalface_alt_tree, frame resident in HBM, 8 calls",
+                            "ms_p50": round(pct(lat, 50), 3), "windows_per_frame": ws,
+                            "windows_per_s": round(ws / (pct(lat, 50) * 1e-3), 1), "detections": len(r.rects)}
+        del d
+    if "5" in which:
+        face, eye = Cascade.load("frontalface_alt2"), Cascade.load("eye")
+        n = 256
+        f = synth.batch(n, 720, 1280, seed0=5001)
+        d = torch.from_numpy(f).cuda()
+        df = DeviceFrames.from_torch(d)
+        env.detect_chain(face, eye, df)
+        lat = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r1, r2 = env.detect_chain(face, eye, df)
+            lat.append((time.perf_counter() - t) * 1e3)
+        ws = face.count_windows(1280, 720)
+        extra["config5"] = {"workload": "256x1280x720, frontalface_alt2 -> haarcascade_eye on every raw face candidate, "
+                                        "regions handed over on the device (vj_detect_chain), frames resident in HBM",
+                            "ms_per_step": round(pct(lat, 50), 3), "frames_per_s": round(n / (pct(lat, 50) * 1e-3), 1),
+                            "face_windows_per_s": round(ws * n / (pct(lat, 50) * 1e-3), 1),
+                            "face_candidates": len(r1.rects), "eye_candidates": len(r2.rects),
+                            "second_cascade_ms": round(r2.cascade_ms, 3)}
+        del d
+    return extra
 
 
 if __name__ == "__main__":

@@ -163,6 +163,8 @@ _SIGNATURES = {
     "vj_result_free": (None, [C.POINTER(_Result)]),
     "vj_group_rectangles": (C.c_int, [C.c_void_p, C.POINTER(C.c_uint32), C.c_int, C.c_double]),
     "vj_count_windows": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.POINTER(C.c_uint64)]),
+    "vj_shard_frames": (C.c_int, [C.c_int, C.c_int, C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "vj_shard_scales": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.POINTER(Params), C.c_int, C.c_int, C.POINTER(C.c_uint64)]),
 }
 
 _lib = None
@@ -281,6 +283,13 @@ class Cascade:
         _check(load_library().vj_plan_feature_table(self._h, width, C.byref(scale), off.ctypes.data,
                                                     wts.ctypes.data), "vj_plan_feature_table")
         return off, wts
+
+    def shard_scales(self, width: int, height: int, rank: int, world: int, params: Params | None = None) -> list[int]:
+        """vj_shard_scales: the scale indices of `rank` when one frame is split over `world` ranks by scale."""
+        p = params or default_params()
+        m = (C.c_uint64 * 2)()
+        _check(load_library().vj_shard_scales(self._h, width, height, C.byref(p), world, rank, m), "vj_shard_scales")
+        return [k for k in range(128) if (m[k >> 6] >> (k & 63)) & 1]
 
     def count_windows(self, width: int, height: int, params: Params | None = None) -> int:
         p = params or default_params()

@@ -63,10 +63,13 @@ void group_rectangles(std::vector<IRect>* rects, int group_threshold, double eps
     std::vector<int> rw(ncls, 0);
     for (size_t i = 0; i < labels.size(); ++i) {
         const int c = labels[i];
-        rr[c].x += (*rects)[i].x;
-        rr[c].y += (*rects)[i].y;
-        rr[c].w += (*rects)[i].w;
-        rr[c].h += (*rects)[i].h;
+        // int accumulators as in the original (tempcv.cpp:167-172); written as unsigned adds so that a (purely
+        // theoretical: > 2^31 of summed coordinates) overflow wraps instead of being undefined
+        auto acc = [](int a, int b) { return (int)((unsigned)a + (unsigned)b); };
+        rr[c].x = acc(rr[c].x, (*rects)[i].x);
+        rr[c].y = acc(rr[c].y, (*rects)[i].y);
+        rr[c].w = acc(rr[c].w, (*rects)[i].w);
+        rr[c].h = acc(rr[c].h, (*rects)[i].h);
         rw[c]++;
     }
     auto sat = [](float v) { return v > (float)INT_MAX ? INT_MAX : (int)v; };
@@ -86,8 +89,9 @@ void group_rectangles(std::vector<IRect>* rects, int group_threshold, double eps
             const IRect r2 = rr[j];
             const int dx = r2.w * eps > INT_MAX ? INT_MAX : (int)(r2.w * eps);
             const int dy = r2.h * eps > INT_MAX ? INT_MAX : (int)(r2.h * eps);
-            if (r1.x >= r2.x - dx && r1.y >= r2.y - dy && r1.x + r1.w <= r2.x + r2.w + dx &&
-                r1.y + r1.h <= r2.y + r2.h + dy && (n2 > std::max(3, n1) || n1 < 3))
+            typedef long long ll;
+            if (r1.x >= (ll)r2.x - dx && r1.y >= (ll)r2.y - dy && (ll)r1.x + r1.w <= (ll)r2.x + r2.w + dx &&
+                (ll)r1.y + r1.h <= (ll)r2.y + r2.h + dy && (n2 > std::max(3, n1) || n1 < 3))
                 break;
         }
         if (j == ncls) {
@@ -102,6 +106,14 @@ void group_rectangles(std::vector<IRect>* rects, int group_threshold, double eps
 
 extern "C" int vj_group_rectangles(vj_rect* rects, uint32_t* count, int group_threshold, double eps) {
     if (!count || (*count && !rects) || !(eps >= 0.0)) return VJ_ERR_ARG;
+    for (uint32_t k = 0; k < *count; ++k) {   // image coordinates: keeps every sum and difference below far inside int
+        const vj_rect& r = rects[k];
+        const int lim = 1 << 20;
+        if (r.x < -lim || r.x > lim || r.y < -lim || r.y > lim || r.w < 0 || r.w > lim || r.h < 0 || r.h > lim) {
+            vj::set_error("rectangle %u is not an image rectangle", k);
+            return VJ_ERR_ARG;
+        }
+    }
     // groups are formed per frame; input order inside a frame is kept (labels depend on it)
     std::vector<vj_rect> out;
     uint32_t i = 0;

@@ -183,6 +183,42 @@ int vj_plan_feature_table(const vj_cascade* c, int width, const vj_scale_info* s
     return VJ_OK;
 }
 
+int vj_shard_frames(int n_frames, int n_ranks, int rank, int* first, int* count) {
+    if (n_frames < 0 || n_ranks <= 0 || rank < 0 || rank >= n_ranks || !first || !count) return VJ_ERR_ARG;
+    const int base = n_frames / n_ranks, extra = n_frames % n_ranks;
+    *first = rank * base + std::min(rank, extra);
+    *count = base + (rank < extra ? 1 : 0);
+    return VJ_OK;
+}
+
+int vj_shard_scales(const vj_cascade* c, int width, int height, const vj_params* p, int n_ranks, int rank, uint64_t scale_mask[2]) {
+    if (!c || !p || !scale_mask || width <= 0 || height <= 0 || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return VJ_ERR_ARG;
+    if (!(p->scale_factor > 1.0f)) return VJ_ERR_ARG;
+    const std::vector<vj_scale_info> sc = plan_scales(*c, width, height, *p);
+    if (sc.size() > 128) {
+        set_error("more than 128 scales cannot be expressed as a scale mask");
+        return VJ_ERR_LIMIT;
+    }
+    std::vector<uint64_t> w(sc.size());
+    std::vector<size_t> order(sc.size());
+    for (size_t k = 0; k < sc.size(); ++k) {
+        w[k] = sc[k].accepted ? (uint64_t)sc[k].nx * (uint64_t)sc[k].ny : 0;
+        order[k] = k;
+    }
+    // longest processing time first; equal counts keep their scale order
+    std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return w[a] > w[b]; });
+    std::vector<uint64_t> load((size_t)n_ranks, 0);
+    scale_mask[0] = scale_mask[1] = 0;
+    for (size_t k : order) {
+        size_t r = 0;
+        for (size_t i = 1; i < load.size(); ++i)
+            if (load[i] < load[r]) r = i;
+        load[r] += w[k];
+        if ((int)r == rank) scale_mask[k >> 6] |= 1ull << (k & 63);
+    }
+    return VJ_OK;
+}
+
 int vj_count_windows(const vj_cascade* c, int width, int height, const vj_params* p, uint64_t* out) {
     if (!c || !p || !out || width <= 0 || height <= 0) return VJ_ERR_ARG;
     if (!(p->scale_factor > 1.0f)) return VJ_ERR_ARG;

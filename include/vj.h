@@ -333,6 +333,20 @@ void vj_stream_destroy(vj_stream* s);
  * MAX(min_neighbors, 1) and eps 0.2 (clod.cpp:11, 1326) when min_neighbors != 0.            */
 int vj_group_rectangles(vj_rect* rects, uint32_t* count, int group_threshold, double eps);
 
+/* ---------------------------------------------------------------- multi-GPU */
+/* One environment per device (clodInitEnvironment(device_index), clod.cpp:72-100), one rank per environment — threads of
+ * one C++ host or processes.  The path shards without a data-path exchange: (frame, scale) pairs are
+ * independent given a frame's integral images.  These two host helpers give every rank its share; the only collective is
+ * the final all-gather of rectangles (include/vj_rccl.h: header-only, RCCL's ncclAllGather, so that this library itself
+ * does not link librccl).
+ * vj_shard_frames: batches with at least as many frames as ranks — contiguous blocks whose sizes differ by at most one.
+ * vj_shard_scales: fewer frames than ranks (one large frame) — every rank integrates the frame and takes a subset of the
+ * scales, longest-processing-time greedy on the window counts (ties to the lower rank); the result goes into
+ * vj_params.scale_mask.                                                                                              */
+int vj_shard_frames(int n_frames, int n_ranks, int rank, int* first, int* count);
+int vj_shard_scales(const vj_cascade* c, int width, int height, const vj_params* p, int n_ranks, int rank,
+                    uint64_t scale_mask[2]);
+
 /* Candidate windows per frame for (cascade, size, params): sum of nx*ny over
  * accepted scales — the denominator of the windows/s metric.                   */
 int vj_count_windows(const vj_cascade* c, int width, int height, const vj_params* p,

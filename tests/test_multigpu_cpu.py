@@ -34,6 +34,26 @@ def test_shard_scales_lpt_balance(oracle, cascades):
     assert frames == [0] and scales is not None
 
 
+def test_native_shard_helpers_agree_with_the_python_ones(lib, cascades):
+    """vj_shard_frames / vj_shard_scales (what a C++ host uses) give the partitions multigpu.shard_frames / shard_scales
+    give: the two N > 1 drivers — bench.py's and examples/multi_gpu — split the work identically."""
+    import ctypes as C
+    for n in (0, 1, 7, 8, 64, 65):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                first, count = C.c_int(), C.c_int()
+                assert lib.vj_shard_frames(n, world, r, C.byref(first), C.byref(count)) == 0
+                assert list(range(first.value, first.value + count.value)) == list(multigpu.shard_frames(n, r, world))
+    assert lib.vj_shard_frames(4, 2, 2, C.byref(first), C.byref(count)) == 1
+    for name, (w, h) in (("frontalface_alt", (1920, 1080)), ("frontalface_alt_tree", (4096, 4096)), ("eye", (300, 200))):
+        c, _ = cascades(name)
+        counts = [s.nx * s.ny if s.accepted else 0 for s in c.plan_scales(w, h)]
+        for world in (1, 2, 4, 8):
+            parts = [c.shard_scales(w, h, r, world) for r in range(world)]
+            assert parts == [multigpu.shard_scales(counts, r, world) for r in range(world)]
+            assert sorted(k for p in parts for k in p) == list(range(len(counts)))
+
+
 def _worker(rank, world, port, mode, q):
     import sys
     import torch.distributed as dist
