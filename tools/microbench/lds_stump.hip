@@ -23,7 +23,7 @@ enum { FULL = 0, NOADD = 1, NOLDS = 2, NOALU = 3 };
 
 template <int VAR>
 __global__ __launch_bounds__(512) void stump_loop(const Rec* table, uint32_t n_recs, uint32_t iters, uint32_t pattern, uint32_t keep_pm,
-                                                  float* out) {
+                                                  float* out, const uint32_t* binned) {
     extern __shared__ uint32_t lds[];
     const uint32_t lane = threadIdx.x & 63u, wib = threadIdx.x >> 6;
     for (uint32_t i = threadIdx.x; i < (uint32_t)TILE_DW; i += 512u) lds[i] = i * 2654435761u >> 8;
@@ -49,6 +49,11 @@ __global__ __launch_bounds__(512) void stump_loop(const Rec* table, uint32_t n_r
             }
             t = idx % 2048u;
             (void)next;
+        } else if (pattern == 3) {
+            // binned: the wave's 256 slots hold survivors (rate keep_pm / 1000 of the wave's share of the tile, wrapped) laid out
+            // residue-major and dealt round-robin over the 8 groups of 32 lanes, so that a group holds at most
+            // ceil(c_r / 8) windows of bank residue r (what a residue-aware re-pack would produce)
+            t = binned[(wib * 256u + c * 64u + lane)];
         } else {
             uint32_t x = (h ^ (lane * 2246822519u) ^ (c * 3266489917u)) * 2654435761u;
             t = (x >> 7) % 2048u;                                                   // unrelated windows
@@ -116,6 +121,30 @@ int main() {
         const float w0 = -1.0f / 324, w1 = 2.0f / 324, thr = 0.01f, l = 0.3f, rr = -0.2f;
         memcpy(&r[8], &w0, 4); memcpy(&r[9], &w1, 4); memcpy(&r[11], &thr, 4); memcpy(&r[12], &l, 4); memcpy(&r[13], &rr, 4);
     }
+    // pattern 3: host-side binning of survivors (one table per keep rate, reused by every workgroup)
+    auto make_binned = [&](uint32_t keep_pm) {
+        std::vector<uint32_t> out(2048, 0);
+        for (uint32_t w = 0; w < 8; ++w) {
+            // survivors of a sparse tile, taken in order until the wave's 256 slots are full
+            std::vector<uint32_t> surv;
+            uint32_t idx = w * 977u, hh = 99u + w;
+            while (surv.size() < 256) {
+                hh = hh * 1664525u + 1013904223u;
+                if ((hh >> 8) % 1000u < keep_pm) surv.push_back(idx % 2048u);
+                ++idx;
+            }
+            std::vector<std::vector<uint32_t>> by_res(32);
+            for (uint32_t t : surv) by_res[(2u * (t / 64u) * PITCH + (t % 64u)) % 32u].push_back(t);
+            uint32_t q = 0;
+            std::vector<std::vector<uint32_t>> groups(8);
+            for (auto& v : by_res) for (uint32_t t : v) groups[(q++) % 8].push_back(t);
+            for (uint32_t g = 0; g < 8; ++g)
+                for (uint32_t i = 0; i < 32; ++i) out[w * 256 + g * 32 + i] = groups[g][i % groups[g].size()];
+        }
+        return out;
+    };
+    uint32_t* d_binned;
+    hipMalloc(&d_binned, 2048 * 4);
     Rec* d_tab;
     float* d_out;
     hipMalloc(&d_tab, recs.size() * 4);
@@ -129,19 +158,24 @@ int main() {
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     struct Pat { const char* name; uint32_t pattern, keep; };
     const Pat pats[] = {{"dense rows (stage 0)", 0, 0}, {"survivors p=0.67 in order", 1, 670}, {"survivors p=0.30 in order", 1, 300},
-                        {"survivors p=0.10 in order", 1, 100}, {"unrelated windows", 2, 0}};
+                        {"survivors p=0.10 in order", 1, 100}, {"unrelated windows", 2, 0}, {"survivors p=0.30 binned", 3, 300},
+                        {"survivors p=0.10 binned", 3, 100}, {"survivors p=0.03 binned", 3, 30}};
     const char* vnames[] = {"full", "no address adds", "no LDS reads", "no arithmetic"};
     for (int wg_per_cu : {1, 2}) {
         for (const Pat& pt : pats) {
             for (int var = 0; var < 4; ++var) {
                 const uint32_t iters = 40;
                 const int blocks = cus * wg_per_cu;
+                if (pt.pattern == 3) {
+                    const std::vector<uint32_t> b = make_binned(pt.keep);
+                    hipMemcpy(d_binned, b.data(), b.size() * 4, hipMemcpyHostToDevice);
+                }
                 auto run = [&]() {
                     switch (var) {
-                        case 0: hipLaunchKernelGGL(stump_loop<FULL>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out); break;
-                        case 1: hipLaunchKernelGGL(stump_loop<NOADD>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out); break;
-                        case 2: hipLaunchKernelGGL(stump_loop<NOLDS>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out); break;
-                        default: hipLaunchKernelGGL(stump_loop<NOALU>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out); break;
+                        case 0: hipLaunchKernelGGL(stump_loop<FULL>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out, d_binned); break;
+                        case 1: hipLaunchKernelGGL(stump_loop<NOADD>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out, d_binned); break;
+                        case 2: hipLaunchKernelGGL(stump_loop<NOLDS>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out, d_binned); break;
+                        default: hipLaunchKernelGGL(stump_loop<NOALU>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out, d_binned); break;
                     }
                 };
                 run();

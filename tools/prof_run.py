@@ -6,6 +6,8 @@ from clfacedetection_amd import Cascade, Environment, DeviceFrames, default_para
 B = int(os.environ.get("B", "8")); R = int(os.environ.get("R", "2"))
 env = Environment(0)
 if os.environ.get("SPLIT") is not None: env.configure("pass_split", os.environ["SPLIT"])
+for kv in os.environ.get("CONFIGURE", "").split(";"):   # e.g. CONFIGURE="tile_binned=0;concurrent=0"
+    if "=" in kv: env.configure(*kv.split("=", 1))
 c = Cascade.load(os.environ.get("CASCADE", "frontalface_alt"))
 frames = synth.batch(B, int(os.environ.get("H", "1080")), int(os.environ.get("W", "1920")), seed0=1)
 t = torch.from_numpy(frames).cuda(); torch.cuda.synchronize()
