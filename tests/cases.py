@@ -30,6 +30,18 @@ DETECT_CASES = [
 # the headline pin: the survey's recorded reference run
 HEADLINE_CASE = ("alt_xs12345_1080", "frontalface_alt", "xorshift", 12345, 1080, 1920, (0, 0), (0, 0), False)
 
+# the other evaluation modes (tests/golden/modes.json): P2 skip variants and the OpenCV arithmetic profile
+MODE_CASES = [  # (id, cascade, generator, seed, height, width)
+    ("m_alt_xs_480", "frontalface_alt", "xorshift", 12345, 480, 640),
+    ("m_alt_smooth", "frontalface_alt", "smooth", 11, 300, 420),
+    ("m_default_blocks", "frontalface_default", "blocks", 6, 360, 480),
+    ("m_alt2_noise", "frontalface_alt2", "noise", 61, 240, 320),
+    ("m_eye_noise", "eye", "noise", 31, 200, 260),
+    ("m_alt_tree_blocks", "frontalface_alt_tree", "blocks", 72, 300, 400),
+    ("m_fullbody_noise", "fullbody", "noise", 81, 240, 320),
+    ("m_eyeglasses_smooth", "eye_tree_eyeglasses", "smooth", 84, 240, 320),
+]
+
 INTEGRAL_CASES = [  # (id, generator, seed, height, width)
     ("i_1x1", "noise", 1, 1, 1), ("i_3x5", "noise", 2, 3, 5), ("i_8x256", "noise", 3, 8, 256),
     ("i_9x257", "noise", 4, 9, 257), ("i_odd", "smooth", 5, 251, 333), ("i_vga", "noise", 6, 480, 640),

@@ -37,6 +37,25 @@ def test_integral_fixture(oracle, g):
     assert not s[0].any() and not s[:, 0].any() and not q[0].any() and not q[:, 0].any()
 
 
+MODES = json.load(open(os.path.join(G, "modes.json")))
+
+
+@pytest.mark.parametrize("g", MODES, ids=lambda d: d["id"])
+def test_mode_fixture(oracle, cascades, g):
+    """The CPU variants' window sets (oracle modes 2 / 3) and the OpenCV-like path, frozen for the GPU box."""
+    _, a = cascades(g["cascade"])
+    img = make_frame(g["generator"], g["seed"], g["height"], g["width"], oracle)
+    assert sha(img) == g["image_sha256"]
+    rows = lambda r: [[int(v) for v in (q["scale_idx"], q["x"], q["y"], q["w"], q["h"])] for q in r]
+    for name, mode in (("skip_list", 2), ("skip_row", 3)):
+        if name in g:
+            r, st = oracle.detect(a, img, mode=mode)
+            assert rows(r) == g[name]["rects"] and st["stage_entered"] == g[name]["stage_entered"]
+    r, st = oracle.detect_opencvlike(a, img)
+    assert sorted(rows(r)) == g["opencv"]["rects"]
+    assert st["windows"] == g["opencv"]["windows"] and st["stage_entered"] == g["opencv"]["stage_entered"]
+
+
 def test_integral_against_numpy_cumsum(oracle):
     img = make_frame("smooth", 9, 67, 129)
     s, q = oracle.integral(img)

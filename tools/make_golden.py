@@ -61,4 +61,23 @@ for casc, W, H, mn, mx in [("frontalface_default", 640, 480, (0, 0), (0, 0)), ("
                    "scales": [[s.scale_idx, float(np.float32(s.scale)).hex(), float(np.float32(s.step)).hex(), s.win_w,
                                s.win_h, s.equ_x, s.equ_w, s.equ_h, s.area, s.nx, s.ny, s.accepted] for s in sc]})
 json.dump(scales, open(os.path.join(G, "scales.json"), "w"), indent=1)
+
+# the other evaluation modes: the CPU variants' window sets (oracle modes 2 and 3) and the OpenCV-like path
+from cases import MODE_CASES  # noqa: E402
+modes = []
+for cid, casc, gen, seed, h, w in MODE_CASES:
+    c = load_vjc(os.path.join(DATA_DIR, f"haarcascade_{casc}.vjc"))
+    img = make_frame(gen, seed, h, w, o)
+    e = {"id": cid, "cascade": casc, "generator": gen, "seed": seed, "height": h, "width": w, "image_sha256": sha(img)}
+    if not c.node_tilted.any() and bool(np.all(c.stage_next == -1)):
+        for name, mode in (("skip_list", 2), ("skip_row", 3)):
+            r, st = o.detect(c, img, mode=mode)
+            e[name] = {"rects": [[int(v) for v in (q["scale_idx"], q["x"], q["y"], q["w"], q["h"])] for q in r],
+                       "stage_entered": st["stage_entered"]}
+    r, st = o.detect_opencvlike(c, img)
+    e["opencv"] = {"rects": sorted([int(v) for v in (q["scale_idx"], q["x"], q["y"], q["w"], q["h"])] for q in r),
+                   "windows": st["windows"], "stage_entered": st["stage_entered"]}
+    modes.append(e)
+    print(cid, {k: len(v["rects"]) for k, v in e.items() if isinstance(v, dict)})
+json.dump(modes, open(os.path.join(G, "modes.json"), "w"), indent=1)
 print("wrote", os.listdir(G))
