@@ -189,6 +189,7 @@ struct CascadeArgs {
     // null = every grid window (the OpenCL kernel's contract)
     unsigned long long* skip_bits;      // [n_frames][skip_frame_words]
     uint32_t  skip_frame_words;
+    uint32_t  gather_pairs;             // global-gather sweeps evaluate two stumps per step: 0 never, 1 when the wave holds one chunk, 2 always
     uint32_t  round_away;               // window positions round(index * step) half away from zero (clod.cpp:1416) instead of lrint (:514)
     const UnitDev* skip_units;          // one per bitmap word of a frame: {scale, first window (flattened index, or ix0 | iy << 16), valid bits, word}
     uint32_t  n_skip_units;

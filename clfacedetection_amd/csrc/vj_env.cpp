@@ -67,7 +67,8 @@ static std::vector<uint32_t> default_pass_bounds(const vj_cascade& c, const Stag
     return b;
 }
 
-static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_params& p, Plan* pl) {
+static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_params& p, Plan* pl, float tile_split) {
+    pl->tile_split = tile_split;
     if ((int)c.stages.size() > VJ_MAX_STAGES) {
         set_error("cascade has %zu stages; at most %d are supported", c.stages.size(), VJ_MAX_STAGES);
         return VJ_ERR_LIMIT;
@@ -299,7 +300,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     // Balance between the two chains: tile_split scales' worth of tile work (counted from the largest tile
     // scale down, fractions by window rows) moves to the global-gather chain, which overlaps the tile chain.
     {
-        double remaining = std::max(0.0, (double)e->tile_split);
+        double remaining = std::max(0.0, (double)tile_split);
         for (size_t k = pl->scales.size(); k-- > 0 && remaining > 0.0;) {
             ScaleDev& sd = pl->scales[k];
             if (!sd.tile_rw) continue;
@@ -525,9 +526,10 @@ static int layout_queues(Plan* pl, int frames, uint64_t* total_entries) {
     return VJ_OK;
 }
 
-static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, Plan** out) {
+static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, Plan** out, int n_frames = 1 << 20) {
+    const float split = e->split_for(n_frames);
     vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
-                        p.scale_mask[1], p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW));
+                        p.scale_mask[1], p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW), f2u(split));
     auto it = e->plans.find(key);
     if (it != e->plans.end()) {
         it->second->last_used = ++e->plan_tick;
@@ -547,7 +549,7 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
         }
     }
     auto pl = std::make_unique<Plan>();
-    int rc = build_plan(e, *c, W, H, p, pl.get());
+    int rc = build_plan(e, *c, W, H, p, pl.get(), split);
     if (rc) {
         pl->release_device();
         return rc;
@@ -845,6 +847,7 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
         ca.tile_ws_min = pl->sp_pad != 0u ? (uint32_t)e->tile_ws_min : 0u;   // no stump-parallel tables: wave-split to the end
         ca.tile_ws_max = (uint32_t)std::min(e->tile_ws_max, (int)TILE_WS_MAX_WINDOWS);
         ca.round_away = pl->skip_mode == VJ_FLAG_SKIP_ROW ? 1u : 0u;
+        ca.gather_pairs = e->pairs_for(nf);
         if (pl->skip_mode && pl->n_skip_units) {
             // the windows the reference's sequential CPU loop visits, as a bitmap: stage-0 verdict of every grid window,
             // then the parity recurrence; the passes below drop the unvisited windows while they enumerate the grid
@@ -1374,6 +1377,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         drop_plans(e);
         return VJ_OK;
     }
+    if (strcmp(key, "gather_pairs") == 0) {
+        e->gather_pairs = std::max(-1, std::min(atoi(value), 2));   // -1: by batch size
+        return VJ_OK;
+    }
     if (strcmp(key, "tile_class_order") == 0) {
         e->tile_class_order = atoi(value) != 0;
         return VJ_OK;
@@ -1435,8 +1442,16 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         e->concurrent_blocks_per_cu = std::max(1, atoi(value));
         return VJ_OK;
     }
-    if (strcmp(key, "tile_split") == 0) {
-        e->tile_split = std::max(0.0f, (float)atof(value));
+    if (strcmp(key, "tile_split") == 0) {   // one value for every batch size, or "small,mid,large" (<= 4, < 32, >= 32 frames)
+        float a = 0, b = 0, c3 = 0;
+        const int n = sscanf(value, "%f,%f,%f", &a, &b, &c3);
+        if (n == 3) {
+            e->tile_split_small = std::max(0.0f, a);
+            e->tile_split_mid = std::max(0.0f, b);
+            e->tile_split = std::max(0.0f, c3);
+        } else {
+            e->tile_split_small = e->tile_split_mid = e->tile_split = std::max(0.0f, (float)atof(value));
+        }
         HIP_TRY(hipStreamSynchronize(e->stream));
         drop_plans(e);
         return VJ_OK;
@@ -1635,7 +1650,7 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
     Plan* pl;
-    rc = get_plan(e, c, W, H, *p, &pl);
+    rc = get_plan(e, c, W, H, *p, &pl, n_frames);
     if (rc) return rc;
     const uint64_t max_frames = max_frames_per_subbatch(e, pl);
     if (max_frames == 0) {
@@ -1739,11 +1754,11 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
     Plan *pl1, *pl2;
-    if ((rc = get_plan(e, first, W, H, *p_first, &pl1))) return rc;
+    if ((rc = get_plan(e, first, W, H, *p_first, &pl1, n_frames))) return rc;
     // the second cascade is planned for the frame's stride and every scale a region as large as the frame could use;
     // each region picks its own scales and grid on the device
     if ((rc = get_plan(e, second, W, H, *p_second, &pl2))) return rc;
-    if ((rc = get_plan(e, first, W, H, *p_first, &pl1))) return rc;   // (the cache may have evicted it for pl2: look it up again)
+    if ((rc = get_plan(e, first, W, H, *p_first, &pl1, n_frames))) return rc;   // (the cache may have evicted it for pl2: look it up again)
     if (pl2->general) {
         set_error("the second cascade of vj_detect_chain must be a linear cascade");
         return VJ_ERR_UNSUPPORTED;
@@ -1818,6 +1833,7 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
             ca.identity_order = 1u;
             ca.tree2 = 0u;
             ca.signed_mean = (p_second->flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
+            ca.gather_pairs = 2u;   // regions are small: thin waves, latency-bound
             ca.stage_entered = (unsigned long long*)(roi_counts + 8);
             HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], e->stream));
             const int hrc = launch_roi_chain(ra, ca, true, pl2->trees, count2, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
@@ -1956,7 +1972,7 @@ int vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int 
         vj_stream* s;
         ~Guard() { if (s) vj_stream_destroy(s); }
     } guard{nullptr};
-    int rc = build_plan(e, *c, width, height, *p, s->plan.get());
+    int rc = build_plan(e, *c, width, height, *p, s->plan.get(), e->split_for(max_batch));
     if (rc) {
         s->plan->release_device();
         return rc;

@@ -88,6 +88,7 @@ struct Plan {
     uint32_t n_sp_blocks = 0;
     int frames_q = 0;  // frames the ScaleDev.q_base/q_cap currently describe
     uint64_t last_used = 0;   // vj_env::plan_tick of the last call that used this plan (LRU eviction)
+    float tile_split = 0.0f;  // the chain balance this plan was built for (vj_env::split_for)
     void release_device() {
         for (DevBuf* b : {&d_table, &d_scales, &d_stages, &d_units, &d_tile_units, &d_sp_blocks, &d_skip_units, &d_skip_segs}) b->release();
     }
@@ -140,7 +141,14 @@ struct vj_env {
     uint32_t det_cap_init = 1u << 16;  // initial capacity of the detection buffer (grows on overflow)
     int concurrent = 1;   // 1: the tile chain and the global-gather chain overlap on two streams
     int concurrent_blocks_per_cu = 1;   // workgroups per CU of the global-gather chain while it overlaps
-    float tile_split = 0.5f;            // scales' worth of tile work handed to the global-gather chain (largest tile scales first)
+    // scales' worth of tile work handed to the global-gather chain (largest tile scales first), by batch size: a single
+    // frame is bound by the latency of the gather chain's thin queue pass (measured, 1080p / frontalface_alt: 1 frame
+    // 1.20 / 1.46 / 1.46 ms at split 0 / 0.5 / 1.25; 4 frames 3.50 / 3.61 / 3.96; 16 frames 12.51 / 12.25 / 12.36;
+    // 64 frames — / 48.0 / 54.0), so small batches keep everything they can on the tiles
+    float tile_split = 0.5f;            // batches of >= 32 frames (with gather_pairs = 2, 1.25 is as good: 48.1 vs 48.0 ms)
+    float tile_split_mid = 0.5f;        // 5 .. 31 frames
+    float tile_split_small = 0.0f;      // <= 4 frames
+    float split_for(int n_frames) const { return n_frames <= 4 ? tile_split_small : n_frames < 32 ? tile_split_mid : tile_split; }
     int xcd_affinity = 1;               // global-gather first pass: one contiguous part of the work per XCD (L2 locality)
     int tile_segments = 1;              // stage trees: tiles run the chains after the prefix themselves
     int general_prefix = 1;             // stage trees: run their linear prefix on the linear kernels (0: one general pass)
@@ -162,7 +170,7 @@ struct vj_env {
     vj::DevBuf d_skip_bits;           // P2 skip modes: visited-window bitmaps of the frames in flight
     vj::DevBuf d_rois, d_roi_units, d_roi_det;   // regions of interest on the device (vj_detect_chain)
     uint32_t roi_unit_cap = 0, roi_det_cap = 0;
-    typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t, uint32_t> PlanKey;
+    typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t, uint32_t, uint32_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<vj::Plan>> plans;
     uint64_t plan_tick = 0;
     int plan_cache_max = 48;      // plans kept per environment; the least recently used one is released beyond that
@@ -188,6 +196,11 @@ struct vj_env {
     int tile_lds_nest = 1;        // LDS blocks of consecutive tile classes nest (k blocks of one = one block of the next)
     int tile_stage_x4 = 1;        // stage tile rows with 16-byte LDS-DMA loads (4x fewer texture-address instructions)
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales
+    int gather_pairs = -1;        // global-gather sweeps evaluate two stumps per step, all their gathers in flight together: 0 never, 1 for
+                                  // waves that hold a single chunk, 2 always, -1 = by batch size: 2 up to 4 frames (a single frame is bound
+                                  // by the LATENCY of thin waves walking 16 stages: queue pass 0.78 -> 0.64 ms), 0 beyond (a faster gather chain
+                                  // only takes issue slots from the tile chain: 64 x 1080p 47.98 / 48.21 / 49.21 ms for 0 / 1 / 2)
+    uint32_t pairs_for(int n_frames) const { return gather_pairs >= 0 ? (uint32_t)gather_pairs : n_frames <= 4 ? 2u : 0u; }
     std::vector<int> split_override;
     std::vector<int> pass_cut_nodes{150};   // default pass cuts, in cumulative nodes
 };

@@ -343,22 +343,49 @@ __device__ __forceinline__ float node_rect_sum(const Img& img, const NodeRecDev&
     return rect_sum;
 }
 
+template <typename Img>
+__device__ __forceinline__ void node_rect_sum_pair(const Img& img, const NodeRecDev& ra, const NodeRecDev& rb, uint32_t off,
+                                                   float& sum_a, float& sum_b);
+
 // One stump-based stage on one window (clod.cl:49-82).  `tab` points at the stage's
-// first node record of the wave's scale; every table value is wave-uniform.
+// first node record of the wave's scale; every table value is wave-uniform.  Two stumps per step: their 16 (24)
+// gathers are issued together, so a wave that walks a stage alone — the thin late stages of the queue passes, a
+// single frame — pays one memory round trip per PAIR instead of one or two per stump (ISA before: 8 loads,
+// s_waitcnt vmcnt(0), 4 loads, s_waitcnt vmcnt(0) per stump); the values are still added in stump order.
 template <typename Img>
 __device__ __forceinline__ float stage_sum_stumps(const Img& img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
-                                                  float var) {
+                                                  float var, bool pairs = true) {
     float stage_sum = 0.0f;
-    NodeRecDev r = tab[0];
-#pragma unroll 2
-    for (uint32_t j = 0; j < n_nodes; ++j) {
-        // fetch the next record while this one is evaluated (scalar loads are long)
-        const NodeRecDev rn = tab[j + 1 < n_nodes ? j + 1 : j];
-        const float norm_threshold = __uint_as_float(r[11]) * var;
+    uint32_t j = 0;
+    if (!pairs) {   // uniform: one stump per step (fewer gathers in flight: gentler on the tile chain next door)
+        NodeRecDev r = tab[0];
+        for (; j < n_nodes; ++j) {
+            const NodeRecDev rn = tab[j + 1 < n_nodes ? j + 1 : j];
+            const float rect_sum = node_rect_sum(img, r, off);
+            stage_sum += (rect_sum >= __uint_as_float(r[11]) * var) ? __uint_as_float(r[13]) : __uint_as_float(r[12]);
+            r = rn;
+        }
+        return stage_sum;
+    }
+    if (n_nodes >= 2u) {
+        NodeRecDev ra = tab[0], rb = tab[1];
+        for (; j + 1u < n_nodes; j += 2u) {
+            // fetch the next pair while this one is evaluated (scalar loads are long)
+            const uint32_t ja = j + 2u < n_nodes ? j + 2u : j, jb = j + 3u < n_nodes ? j + 3u : j + 1u;
+            const NodeRecDev na = tab[ja], nb = tab[jb];
+            float sa, sb;
+            node_rect_sum_pair(img, ra, rb, off, sa, sb);
+            // alpha[rect_sum >= norm_threshold]: alpha[0] = left_val, alpha[1] = right_val
+            stage_sum += (sa >= __uint_as_float(ra[11]) * var) ? __uint_as_float(ra[13]) : __uint_as_float(ra[12]);
+            stage_sum += (sb >= __uint_as_float(rb[11]) * var) ? __uint_as_float(rb[13]) : __uint_as_float(rb[12]);
+            ra = na;
+            rb = nb;
+        }
+    }
+    if (j < n_nodes) {   // odd tail
+        const NodeRecDev r = tab[j];
         const float rect_sum = node_rect_sum(img, r, off);
-        // alpha[rect_sum >= norm_threshold]: alpha[0] = left_val, alpha[1] = right_val
-        stage_sum += (rect_sum >= norm_threshold) ? __uint_as_float(r[13]) : __uint_as_float(r[12]);
-        r = rn;
+        stage_sum += (rect_sum >= __uint_as_float(r[11]) * var) ? __uint_as_float(r[13]) : __uint_as_float(r[12]);
     }
     return stage_sum;
 }
@@ -466,9 +493,9 @@ __device__ __forceinline__ float stage_sum_trees(const Img& img, kptr<NodeRecDev
 
 template <bool TREES, typename Img>
 __device__ __forceinline__ float stage_sum_of(const Img& img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
-                                              float var) {
+                                              float var, bool pairs = true) {
     if (TREES) return stage_sum_trees(img, tab, n_nodes, off, var);
-    return stage_sum_stumps(img, tab, n_nodes, off, var);
+    return stage_sum_stumps(img, tab, n_nodes, off, var, pairs);
 }
 
 // Compacting stage sweep shared by every pass: runs stages [a.stage_begin, a.stage_end)
@@ -565,7 +592,7 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
                     stage_sum_tree2_multi<1>(img, tab, n_nodes >> 1, off1, var1, sum1);
                     pass = sum1[0] >= threshold;
                 } else {
-                    pass = stage_sum_of<TREES>(img, tab, n_nodes, e.off, e.var) >= threshold;
+                    pass = stage_sum_of<TREES>(img, tab, n_nodes, e.off, e.var, a.gather_pairs == 2u || (a.gather_pairs == 1u && n <= 64u)) >= threshold;
                 }
             }
             if (!MULTI && fail.base != nullptr) {   // uniform: this segment's rejects continue elsewhere

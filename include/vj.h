@@ -172,12 +172,13 @@ int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
  * acceptable / a scale eligible for tiles, "tile_lds_reserve_kb" = LDS per CU left
  * to the global-gather chain, "concurrent" = 0/1 overlap the two chains on two
  * streams, "concurrent_blocks_per_cu", "tile_split" = scales' worth of tile work
- * handed to the gather chain, "grid_block_w" = width of the 2-D window blocks of the
+ * handed to the gather chain (one value, or "small,mid,large" for batches of <= 4, < 32, >= 32 frames), "grid_block_w" = width of the 2-D window blocks of the
  * gather chain's first pass (0: row runs), "global_blocks" = 0/1 large scales as
  * unstaged blocks in the tile kernel, "tile_repack" = stages before which a tile
  * re-packs, "tile_finish" (0 stump-parallel only, 1 wave-split first),
  * "tile_sp_begin", "tile_sp_max", "tile_ws_min", "tile_ws_max" = finish
- * thresholds, "tile_deinterleave", "tile_min_lanes", "max_subbatch", "det_cap".
+ * thresholds, "tile_deinterleave", "tile_min_lanes", "max_subbatch", "det_cap", "gather_pairs" (stumps per step of the
+ * global-gather sweeps: 0 one, 1 two for thin waves, 2 two always, -1 by batch size), "plan_cache_max".
  * Unknown keys return VJ_ERR_ARG.                                               */
 int  vj_env_configure(vj_env* e, const char* key, const char* value);
 

@@ -140,7 +140,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("concurrent", 1)
         env.configure("tile_lds_reserve_kb", 16)
         env.configure("global_blocks", 0)
-        env.configure("tile_split", 0.5)
+        env.configure("tile_split", "0,0.5,0.5")
         env.configure("grid_block_w", 32)
         # LDS-tile path off / small / large tiles / shallow / deep: the tile and the
         # global-gather paths agree bit for bit
@@ -164,7 +164,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("concurrent", 1)
         env.configure("tile_lds_reserve_kb", 16)
         env.configure("global_blocks", 0)
-        env.configure("tile_split", 0.5)
+        env.configure("tile_split", "0,0.5,0.5")
         env.configure("grid_block_w", 32)
         env.configure("pass_split", "")
         env.configure("blocks_per_cu", 8)

@@ -26,7 +26,7 @@ from clfacedetection_amd import Cascade, DeviceFrames, Environment, VJ_FLAG_COUN
 DEFAULTS = {"pass_split": "", "blocks_per_cu": 8, "tile_classes_kb": "-2,-1,0", "tile_min_windows": 768,
             "tile_accept_windows": 768, "tile_end": 64, "tile_sp_begin": 3, "tile_sp_max": 192, "tile_finish": 1,
             "tile_ws_max": 512, "tile_ws_min": 48, "concurrent": 1, "concurrent_blocks_per_cu": 1,
-            "tile_lds_reserve_kb": 16, "tile_split": 0.5, "grid_block_w": 32, "xcd_affinity": 1, "global_blocks": 0}
+            "tile_lds_reserve_kb": 16, "tile_split": "0,0.5,0.5", "grid_block_w": 32, "xcd_affinity": 1, "global_blocks": 0}
 
 env = Environment(0)
 casc = Cascade.load("frontalface_alt")
