@@ -189,6 +189,8 @@ struct CascadeArgs {
     // null = every grid window (the OpenCL kernel's contract)
     unsigned long long* skip_bits;      // [n_frames][skip_frame_words]
     uint32_t  skip_frame_words;
+    uint32_t  sp_tail_max;              // global-gather sweeps: at most this many windows left in a wave -> stump-parallel tail (0: off; <= 48)
+    uint32_t  max_stage_nodes;          // nodes of the cascade's largest stage
     uint32_t  gather_pairs;             // global-gather sweeps evaluate two stumps per step: 0 never, 1 when the wave holds one chunk, 2 always
     uint32_t  round_away;               // window positions round(index * step) half away from zero (clod.cpp:1416) instead of lrint (:514)
     const UnitDev* skip_units;          // one per bitmap word of a frame: {scale, first window (flattened index, or ix0 | iy << 16), valid bits, word}

@@ -284,6 +284,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         pl->stages.push_back(sd);
     }
     pl->n_order = (uint32_t)order.size();
+    for (size_t s2 = 0; s2 < c.stages.size(); ++s2) pl->max_stage_nodes = std::max(pl->max_stage_nodes, pl->prog.n_nodes[s2]);
     // blocks of <= 64 consecutive nodes per stage, balanced, for the stump-parallel finish of the tile kernel
     std::vector<SpBlock> sp_blocks;
     for (size_t s = 0; s < c.stages.size(); ++s) {
@@ -368,8 +369,14 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
             std::vector<int> seg_first_pass;
             for (const Seg& sg : segs) {
                 seg_first_pass.push_back((int)bounds.size() - 1);
+                // cuts inside a chain: after its third stage (most of its windows are gone by then) and, when the chain is
+                // long and launches are left, once more after its seg_cut2-th — the survivors are re-packed chip-wide at
+                // every cut instead of riding on in thin waves
                 const uint32_t cut = sg.e - sg.b > 4 ? sg.b + 3 : sg.e;
                 if (cut < sg.e) { bounds.push_back(cut); last.push_back(0); failq.push_back(0); }
+                const uint32_t cut2 = e->seg_cut2 > 3 && sg.e - sg.b > (uint32_t)e->seg_cut2 + 4u && bounds.size() + 2 * (segs.size() - seg_first_pass.size()) + 1 < (size_t)VJ_MAX_PASSES
+                                          ? sg.b + (uint32_t)e->seg_cut2 : sg.e;
+                if (cut2 < sg.e) { bounds.push_back(cut2); last.push_back(0); failq.push_back(0); }
                 bounds.push_back(sg.e); last.push_back(1); failq.push_back(0);
             }
             if (ok && !segs.empty() && bounds.size() - 1 <= (size_t)VJ_MAX_PASSES) {
@@ -848,6 +855,8 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
         ca.tile_ws_max = (uint32_t)std::min(e->tile_ws_max, (int)TILE_WS_MAX_WINDOWS);
         ca.round_away = pl->skip_mode == VJ_FLAG_SKIP_ROW ? 1u : 0u;
         ca.gather_pairs = e->pairs_for(nf);
+        ca.sp_tail_max = (uint32_t)std::max(0, std::min(e->sp_tail_max, 48));
+        ca.max_stage_nodes = pl->max_stage_nodes;
         if (pl->skip_mode && pl->n_skip_units) {
             // the windows the reference's sequential CPU loop visits, as a bitmap: stage-0 verdict of every grid window,
             // then the parity recurrence; the passes below drop the unvisited windows while they enumerate the grid
@@ -1377,6 +1386,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         drop_plans(e);
         return VJ_OK;
     }
+    if (strcmp(key, "sp_tail_max") == 0) {
+        e->sp_tail_max = std::max(0, std::min(atoi(value), 48));
+        return VJ_OK;
+    }
     if (strcmp(key, "gather_pairs") == 0) {
         e->gather_pairs = std::max(-1, std::min(atoi(value), 2));   // -1: by batch size
         return VJ_OK;
@@ -1458,6 +1471,12 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "xcd_affinity") == 0) {
         e->xcd_affinity = atoi(value) != 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "seg_cut2") == 0) {   // stage trees: second cut inside a long chain, after this many of its stages (0: none)
+        e->seg_cut2 = std::max(0, atoi(value));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
         return VJ_OK;
     }
     if (strcmp(key, "tile_segments") == 0) {
@@ -1834,6 +1853,8 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
             ca.tree2 = 0u;
             ca.signed_mean = (p_second->flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
             ca.gather_pairs = 2u;   // regions are small: thin waves, latency-bound
+            ca.sp_tail_max = (uint32_t)std::max(0, std::min(e->sp_tail_max, 48));
+            ca.max_stage_nodes = pl2->max_stage_nodes;
             ca.stage_entered = (unsigned long long*)(roi_counts + 8);
             HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], e->stream));
             const int hrc = launch_roi_chain(ra, ca, true, pl2->trees, count2, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);

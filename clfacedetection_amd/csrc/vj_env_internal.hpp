@@ -80,6 +80,7 @@ struct Plan {
     // the same chains for the tile kernel, which runs them itself when chain k's rejects feed chain k+1
     uint32_t tile_n_seg = 0, tile_seg_end[4] = {}, tile_seg_chain = 0;
     uint32_t n_order = 0;  // stages reachable from stage 0, in StageDev::order
+    uint32_t max_stage_nodes = 0;
     StageProgram prog;
     // device copies
     DevBuf d_table, d_scales, d_stages, d_units, d_tile_units, d_sp_blocks, d_skip_units, d_skip_segs;
@@ -151,6 +152,7 @@ struct vj_env {
     float split_for(int n_frames) const { return n_frames <= 4 ? tile_split_small : n_frames < 32 ? tile_split_mid : tile_split; }
     int xcd_affinity = 1;               // global-gather first pass: one contiguous part of the work per XCD (L2 locality)
     int tile_segments = 1;              // stage trees: tiles run the chains after the prefix themselves
+    int seg_cut2 = 0;                   // stage trees: a second cut inside a long chain after this many of its stages (0: none)
     int general_prefix = 1;             // stage trees: run their linear prefix on the linear kernels (0: one general pass)
     int grid_block_w = 32;              // width of the 2-D window blocks of the global-gather first pass (0: row runs)
     int global_blocks = 0;              // 1: large scales run as unstaged 2-D blocks in the tile kernel (stump cascades): 2.2x
@@ -196,6 +198,7 @@ struct vj_env {
     int tile_lds_nest = 1;        // LDS blocks of consecutive tile classes nest (k blocks of one = one block of the next)
     int tile_stage_x4 = 1;        // stage tile rows with 16-byte LDS-DMA loads (4x fewer texture-address instructions)
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales
+    int sp_tail_max = 48;         // global-gather sweeps switch to the stump-parallel tail when a wave holds at most this many windows (0: never)
     int gather_pairs = -1;        // global-gather sweeps evaluate two stumps per step, all their gathers in flight together: 0 never, 1 for
                                   // waves that hold a single chunk, 2 always, -1 = by batch size: 2 up to 4 frames (a single frame is bound
                                   // by the LATENCY of thin waves walking 16 stages: queue pass 0.78 -> 0.64 ms), 0 beyond (a faster gather chain

@@ -509,6 +509,83 @@ struct FailSink {
     uint32_t* count = nullptr;
 };
 
+// Thin-wave tail of a global-gather sweep (stump cascades).  Once a wave is down to a handful of windows, walking a
+// stage stump by stump costs one scalar record fetch and one memory round trip per stump (pair) with 1-8 of its 64
+// lanes busy — a late stage of 100-400 stumps takes 0.1-1 ms per wave whatever the population, which is what bounds a
+// single frame and the late passes of a stage tree.  So the roles are turned around: lane j takes stump j of a block of 64
+// (its record arrives with four coalesced 16-byte loads), every window is evaluated by all lanes at once (the window
+// offset is wave-uniform, the corner offsets differ per lane: GlobalImgByStump), a __ballot gives the block's verdict
+// bits, and afterwards lane w adds window w's leaf values IN STUMP ORDER from the bits — the reference's sequence of f32
+// additions (clod.cl:81; the leaf values come through the scalar cache).  Scratch: the unused part of the wave's LDS
+// queue (the verdict words).  Per stage the cost is windows x blocks instead of stumps, so it pays below ~64 windows.
+constexpr uint32_t SP_TAIL_MAX = 48;          // windows at most: 48 entries (384 B) + 48 x 9 verdict words (3456 B) fit the wave's 4 KiB queue
+constexpr uint32_t SP_TAIL_MAX_BLOCKS = 9;    // blocks of 64 stumps per stage at most (stages of <= 576 nodes)
+constexpr uint32_t SP_TAIL_MAX_NODES = SP_TAIL_MAX_BLOCKS * 64u;
+
+template <bool COUNT>
+__device__ __forceinline__ uint32_t sweep_tail_stump_parallel(const CascadeArgs& a, rsrc_t img_r, kptr<NodeRecDev> table, QEntry* q, uint32_t n,
+                                                              uint32_t lane, uint32_t begin, uint32_t end, FailSink fail) {
+    kptr<StageDev> stages = as_k(a.stages);
+    const GlobalImgByStump img{img_r};
+    unsigned long long* masks = reinterpret_cast<unsigned long long*>(q + SP_TAIL_MAX);          // [window][block]
+    for (uint32_t pos = begin; pos < end && n != 0u; ++pos) {
+        const uint32_t s = a.identity_order != 0u ? pos : stages[pos].order;
+        const uint32_t first_node = stages[s].first_node, n_nodes = stages[s].n_nodes;
+        const float threshold = stages[s].threshold;
+        if (COUNT && lane == 0) atomicAdd(a.stage_entered + s, (unsigned long long)n);
+        const uint32_t n_blocks = (n_nodes + 63u) >> 6;
+        // A: verdict bits, lanes = stumps
+        for (uint32_t b = 0; b < n_blocks; ++b) {
+            const uint32_t j = b * 64u + lane;
+            const bool active = j < n_nodes;
+            const uint4* rp = reinterpret_cast<const uint4*>((uintptr_t)(table + first_node + (active ? j : 0u)));
+            const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+            NodeRecDev r;
+            r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
+            r[8] = r2.x; r[9] = r2.y; r[10] = r2.z; r[11] = r2.w; r[12] = r3.x; r[13] = r3.y; r[14] = r3.z; r[15] = r3.w;
+            const float thr_node = __uint_as_float(r[11]);
+            for (uint32_t w = 0; w < n; ++w) {
+                const QEntry e = q[w];   // broadcast
+                const float sum = node_rect_sum(img, r, e.off);
+                const unsigned long long m = __ballot(active && sum >= thr_node * e.var);
+                if (lane == 0) masks[w * SP_TAIL_MAX_BLOCKS + b] = m;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+        // B: lanes = windows; leaf values added in stump order
+        const bool have = lane < n;
+        const QEntry mine = q[have ? lane : 0u];
+        float stage_sum = 0.0f;
+        kptr<uint32_t> leaf = reinterpret_cast<kptr<uint32_t>>(table + first_node);   // record k: dwords 12 / 13 = left / right value
+        for (uint32_t b = 0; b < n_blocks; ++b) {
+            const unsigned long long m = masks[(have ? lane : 0u) * SP_TAIL_MAX_BLOCKS + b];
+            const uint32_t jn = min(64u, n_nodes - b * 64u);
+#pragma unroll 4
+            for (uint32_t k = 0; k < jn; ++k) {
+                const uint32_t j = b * 64u + k;
+                const float l = __uint_as_float(leaf[j * 16u + 12u]), rr = __uint_as_float(leaf[j * 16u + 13u]);
+                stage_sum += ((m >> k) & 1ull) != 0ull ? rr : l;
+            }
+        }
+        const bool pass = have && stage_sum >= threshold;
+        if (fail.base != nullptr) {   // uniform: this segment's rejects continue elsewhere
+            const unsigned long long fm = __ballot(have && !pass);
+            if (fm != 0ull) {
+                uint32_t g = 0;
+                if (lane == 0) g = atomicAdd(fail.count, (uint32_t)__popcll(fm));
+                g = __builtin_amdgcn_readfirstlane(g);
+                if (have && !pass) fail.base[g + mbcnt(fm)] = mine;
+            }
+        }
+        const unsigned long long pm = __ballot(pass);
+        __builtin_amdgcn_wave_barrier();   // every lane holds its entry and has read its masks
+        if (pass) q[mbcnt(pm)] = mine;
+        n = (uint32_t)__popcll(pm);
+        __builtin_amdgcn_wave_barrier();
+    }
+    return n;
+}
+
 template <bool TREES, bool COUNT, bool MULTI = false, typename Img>
 __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img& img, kptr<NodeRecDev> table,
                                                  QEntry* q, uint32_t n, uint32_t lane, uint32_t begin, uint32_t end,
@@ -519,6 +596,11 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
         const uint32_t s = a.identity_order != 0u ? pos : stages[pos].order;   // (no dependent load for linear cascades)
         const uint32_t first_node = stages[s].first_node;
         const uint32_t n_nodes = stages[s].n_nodes;
+        if constexpr (!TREES && !MULTI && std::is_same<Img, GlobalImg>::value) {
+            // a handful of windows left: the rest of the sweep stump-parallel (uniform decision)
+            if (a.sp_tail_max != 0u && n <= a.sp_tail_max && a.max_stage_nodes <= SP_TAIL_MAX_NODES)
+                return sweep_tail_stump_parallel<COUNT>(a, img.r, table, q, n, lane, pos, end, fail);
+        }
         const float threshold = stages[s].threshold;
         if (COUNT && lane == 0) atomicAdd(a.stage_entered + s, (unsigned long long)n);
         kptr<NodeRecDev> tab = table + first_node;
