@@ -121,3 +121,24 @@ def cascade_to_product(c):
     nd["tilted"] = c.node_tilted if len(c.node_tilted) == c.n_nodes else 0
     nd["threshold"], nd["left"], nd["right"] = c.node_threshold, c.node_left, c.node_right
     return Cascade.from_arrays(c.win_w, c.win_h, st, tr, nd, c.alpha)
+
+
+def as_stage_tree(c, split_at: int = 4):
+    """A copy of a linear cascade re-linked like frontalface_alt_tree: stages 0..split_at form a chain, then two
+    chains alternate (split_at+1, +3, +5, ... and split_at+2, +4, ...), the second one taking over when the first rejects
+    (parent / next / child as icvReadHaarClassifier would have set them)."""
+    import copy
+    t = copy.deepcopy(c)
+    n = t.n_stages
+    parent = np.full(n, -1, np.int32)
+    nxt = np.full(n, -1, np.int32)
+    for i in range(1, n):
+        parent[i] = i - 1 if i <= split_at + 1 else i - 2
+    parent[split_at + 2] = split_at
+    nxt[split_at + 1] = split_at + 2
+    child = np.full(n, -1, np.int32)
+    for i in range(n):
+        if parent[i] != -1 and child[parent[i]] == -1:
+            child[parent[i]] = i
+    t.stage_parent, t.stage_next, t.stage_child = parent, nxt, child
+    return t
