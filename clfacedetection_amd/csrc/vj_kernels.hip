@@ -667,7 +667,7 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
             const QEntry e = q[act ? i : 0u];
             bool pass = false;
             if (act) {
-                if (TREES && MULTI && a.tree2) {
+                if (TREES && a.tree2) {   // two-node trees: both nodes' gathers in flight (tile sweeps and global-gather sweeps alike)
                     const uint32_t off1[1] = {e.off};
                     const float var1[1] = {e.var};
                     float sum1[1];
