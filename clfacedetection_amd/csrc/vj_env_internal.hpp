@@ -99,10 +99,6 @@ struct Plan {
 
 namespace vj {
 
-struct LaunchNote {   // one kernel launch of the batch in flight, for vj_timing
-    vj_launch info;
-};
-
 // Everything ONE batch in flight owns: its frames on the device, its counters / detections and their host copies, and
 // the events that time it.  vj_detect uses the environment's own lane; a vj_stream owns two, so that the upload of
 // batch k+1 can run while the kernels of batch k do.  Integral images, survivor queues and plans are shared: the
