@@ -271,7 +271,9 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             a.frame_elems = frame_elems;
             a.stride = stride;
             a.sum_h = (uint32_t)H + 1u;
-            const int n_blocks = std::max(1, e->n_cu * e->blocks_per_cu);
+            // four workgroups (16 waves) per CU: every wave walks its own window row, and the rows in flight on an XCD
+            // should stay inside its 4 MiB L2 (64 x 1080p: 376 / 235 / 179 / 153 / 173 / 194 / 193 ms for 1 / 2 / 3 / 4 / 5 / 6 / 8)
+            const int n_blocks = std::max(1, e->n_cu * 4);
             a.total_waves = (uint32_t)n_blocks * CV_WAVES_PER_BLOCK;
             a.det = (CvDet*)d_det.p;
             a.det_count = (uint32_t*)((unsigned long long*)d_counts.p + 2 * VJ_MAX_STAGES);

@@ -5,7 +5,9 @@ from clfacedetection_amd import Cascade, Environment, DeviceFrames, synth
 env = Environment(0)
 t = torch.from_numpy(synth.batch(64, 1080, 1920, seed0=1)).cuda(); torch.cuda.synchronize()
 df = DeviceFrames.from_torch(t)
-for name in ("frontalface_alt", "frontalface_alt_tree", "fullbody"):
+for kv in sys.argv[1:]:
+    env.configure(*kv.split("=", 1))
+for name in ("frontalface_alt",):
     c = Cascade.load(name)
     env.detect_opencv(c, df)
     ts = []
