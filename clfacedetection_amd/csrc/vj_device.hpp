@@ -250,6 +250,36 @@ struct RoiArgs {
     uint32_t det_cap;
 };
 int launch_roi_chain(const RoiArgs& r, const CascadeArgs& a, bool from_dets, bool trees, bool count, int n_blocks, void* stream);
+
+// Grouping of a first cascade's raw candidates on the device (vj_detect_chain with min_neighbors != 0): the grouped
+// rectangles become the region list of the second cascade without a host round trip (vj_group_dev.hip).
+constexpr uint32_t GROUP_MAX = 2048;   // raw candidates of ONE frame the device kernel groups; beyond that the host path runs
+struct GroupArgs {
+    const DetEntry* det;         // the first cascade's detection buffer (device order)
+    const uint32_t* det_count;
+    uint32_t det_cap;
+    const ScaleDev* scales;      // the first cascade's scales (win_w / win_h)
+    uint32_t frame_bytes;        // frame_elems * 4
+    uint32_t stride;             // W + 1
+    uint32_t n_frames;
+    int32_t  threshold;          // MAX(min_neighbors, 1)
+    double   eps;                // 0.2 (clod.cpp:11)
+    uint32_t* frame_count;       // [n_frames]      raw candidates per frame          } one block, zeroed by the
+    uint32_t* frame_cursor;      // [n_frames]      scatter cursors                   } launcher
+    uint32_t* grouped_count;     // [n_frames]      grouped rectangles per frame      }
+    uint32_t* overflow;          // [1]             frames with more than GROUP_MAX   }
+    uint32_t* frame_first;       // [n_frames + 1]  exclusive prefix of frame_count
+    uint64_t* keys;              // [det_cap]       candidates bucketed by frame: scale slot << 32 | element index in the frame
+    RoiDev*   grouped;           // [det_cap]       per-frame segments (at frame_first[frame])
+    uint32_t* grouped_weight;    // [det_cap]
+    RoiDev*   rois;              // out: the region list, frames in order
+    uint32_t* roi_weight;        // out: members of every group
+    uint32_t* n_rois;            // out (device)
+    uint32_t  max_rois;
+    uint32_t  group_max;         // <= GROUP_MAX
+};
+int launch_group_rois(const GroupArgs& g, void* stream);
+int prepare_group_kernels();   // per device: dynamic-LDS cap of group_frame
 int launch_skip_bitmap(const CascadeArgs& a, bool trees, int n_blocks, void* stream);   // fail bits, then the visited bitmap
 int prepare_tile_kernels();   // per device: raise the dynamic-LDS cap of the tile kernel's instantiations
 

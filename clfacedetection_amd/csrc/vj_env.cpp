@@ -1151,6 +1151,20 @@ static int detect_subbatch(vj_env* e, Plan* pl, const vj_image* frames, int f0, 
 }
 
 // Sort, widen and (optionally) group the decoded detections of a whole call; fill the counters.
+static void fill_counters(Plan* pl, int n_frames, const vj_params& p, vj_result* out) {
+    if (!(p.flags & VJ_FLAG_COUNTERS)) return;
+    vj_counters& k = out->counters;
+    k.windows = pl->windows_per_frame * (uint64_t)n_frames;
+    uint64_t rect_evals = 0;
+    for (size_t s = 0; s < pl->stages.size(); ++s) {
+        // exact for stump cascades; for multi-node trees this is the upper bound
+        // (every node of every tree) — see DESIGN.md
+        k.stump_evals += k.stage_entered[s] * pl->prog.n_nodes[s];
+        rect_evals += k.stage_entered[s] * pl->prog.n_rects[s];
+    }
+    k.gather_bytes = 48ull * k.windows + 16ull * rect_evals;
+}
+
 static int build_result(Plan* pl, std::vector<RawDet>& dets, int n_frames, const vj_params& p, vj_result* out) {
     // deterministic order: (frame, scale_idx, y, x)
     std::sort(dets.begin(), dets.end(), [](const RawDet& a, const RawDet& b) {
@@ -1170,18 +1184,7 @@ static int build_result(Plan* pl, std::vector<RawDet>& dets, int n_frames, const
         const int rc = vj_group_rectangles(out->rects, &out->count, (int)std::max<uint32_t>(p.min_neighbors, 1u), 0.2);
         if (rc) return rc;
     }
-    if (p.flags & VJ_FLAG_COUNTERS) {
-        vj_counters& k = out->counters;
-        k.windows = pl->windows_per_frame * (uint64_t)n_frames;
-        uint64_t rect_evals = 0;
-        for (size_t s = 0; s < pl->stages.size(); ++s) {
-            // exact for stump cascades; for multi-node trees this is the upper bound
-            // (every node of every tree) — see DESIGN.md
-            k.stump_evals += k.stage_entered[s] * pl->prog.n_nodes[s];
-            rect_evals += k.stage_entered[s] * pl->prog.n_rects[s];
-        }
-        k.gather_bytes = 48ull * k.windows + 16ull * rect_evals;
-    }
+    fill_counters(pl, n_frames, p, out);
     return VJ_OK;
 }
 
@@ -1263,6 +1266,10 @@ int vj_env_create(int device_index, vj_env** out) {
         set_error("raising the dynamic LDS limit on device %d failed: %s", device_index, hipGetErrorString((hipError_t)hrc));
         return VJ_ERR_HIP;
     }
+    if (const int hrc = prepare_group_kernels()) {
+        set_error("raising the dynamic LDS limit on device %d failed: %s", device_index, hipGetErrorString((hipError_t)hrc));
+        return VJ_ERR_HIP;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&e->stream, hipStreamNonBlocking));
     { const int lrc = e->lane0.create(); if (lrc) return lrc; }
     HIP_TRY(hipEventCreateWithFlags(&e->fork_ev, hipEventDisableTiming));
@@ -1288,7 +1295,7 @@ void vj_env_destroy(vj_env* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     drop_plans(e);
     for (DevBuf* b : {&e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_tilted, &e->d_out,
-                      &e->d_skip_bits, &e->d_rois, &e->d_roi_units, &e->d_roi_det})
+                      &e->d_skip_bits, &e->d_rois, &e->d_roi_units, &e->d_roi_det, &e->d_group})
         b->release();
     e->lane0.destroy();
     for (DevBuf& b : e->d_q) b.release();
@@ -1384,6 +1391,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         e->tile_lds_nest = atoi(value) != 0;
         HIP_TRY(hipStreamSynchronize(e->stream));
         drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "group_max") == 0) {
+        e->group_max = std::max(1, std::min(atoi(value), (int)GROUP_MAX));
         return VJ_OK;
     }
     if (strcmp(key, "sp_tail_max") == 0) {
@@ -1762,12 +1773,11 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
         set_error("scale_factor must be > 1");
         return VJ_ERR_ARG;
     }
-    if (p_first->min_neighbors != 0 || (p_first->flags | p_second->flags) & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW) ||
-        (p_second->scale_mask[0] | p_second->scale_mask[1]) != 0) {
-        set_error("vj_detect_chain hands RAW candidates over on the device: min_neighbors of the first cascade, the skip modes and a "
-                  "scale mask on the second cascade are not supported");
+    if ((p_first->flags | p_second->flags) & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW) || (p_second->scale_mask[0] | p_second->scale_mask[1]) != 0) {
+        set_error("vj_detect_chain: the skip modes and a scale mask on the second cascade are not supported");
         return VJ_ERR_UNSUPPORTED;
     }
+    const bool grouped = p_first->min_neighbors != 0;   // the regions are the GROUPED candidates (grouped on the device)
     int W, H, CH;
     int rc = check_frames(frames, n_frames, &W, &H, &CH);
     if (rc) return rc;
@@ -1793,6 +1803,7 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
     }
     Lane* L = &e->lane0;
     std::vector<RawDet> dets1;
+    std::vector<vj_rect> grouped1;       // grouped mode: the first result, as the device grouped it
     struct Det2 { int roi; uint32_t slot, x, y; };
     std::vector<Det2> dets2;
     const bool count2 = (p_second->flags & VJ_FLAG_COUNTERS) != 0;
@@ -1804,11 +1815,45 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
         if (e->roi_unit_cap == 0) e->roi_unit_cap = 1u << 18;
         if (e->roi_det_cap == 0) e->roi_det_cap = 1u << 16;
         uint32_t n_det1 = 0, n_units = 0, n_det2 = 0;
+        size_t roi_weight_off = 0;   // grouped mode: where the groups' member counts sit in d_group
         float ms_roi = 0;
         bool ok = false;
         for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
             if ((rc = enqueue_cascade(e, L, pl1, W, H, *p_first))) return rc;
             if ((rc = e->d_rois.ensure((size_t)L->det_cap * sizeof(RoiDev)))) return rc;
+            GroupArgs ga;
+            memset(&ga, 0, sizeof(ga));
+            if (grouped) {
+                // one buffer: keys (u64) | grouped | the zeroed counter block | frame_first | weights
+                const size_t cap = L->det_cap, nfz = (size_t)nf;
+                const size_t o_keys = 0, o_grouped = o_keys + cap * 8u, o_zero = o_grouped + cap * sizeof(RoiDev),
+                             o_first = o_zero + (3u * nfz + 1u) * 4u, o_gw = o_first + (nfz + 1u) * 4u, o_rw = o_gw + cap * 4u,
+                             total = o_rw + cap * 4u;
+                if ((rc = e->d_group.ensure(total))) return rc;
+                char* gb = (char*)e->d_group.p;
+                ga.det = (const DetEntry*)L->d_det.p;
+                ga.det_count = (const uint32_t*)L->d_counts.p + MAX_PASSES * CountsLayout::q_counts;
+                ga.det_cap = L->det_cap;
+                ga.scales = (const ScaleDev*)pl1->d_scales.p;
+                ga.frame_bytes = pl1->frame_elems * 4u;
+                ga.stride = stride;
+                ga.n_frames = (uint32_t)nf;
+                ga.threshold = (int32_t)std::max<uint32_t>(p_first->min_neighbors, 1u);   // clod.cpp:1326
+                ga.eps = 0.2;                                                               // clod.cpp:11
+                ga.keys = (uint64_t*)(gb + o_keys);
+                ga.grouped = (RoiDev*)(gb + o_grouped);
+                ga.frame_count = (uint32_t*)(gb + o_zero);
+                ga.frame_cursor = ga.frame_count + nfz;
+                ga.grouped_count = ga.frame_cursor + nfz;
+                ga.overflow = ga.grouped_count + nfz;
+                ga.frame_first = (uint32_t*)(gb + o_first);
+                ga.grouped_weight = (uint32_t*)(gb + o_gw);
+                ga.roi_weight = (uint32_t*)(gb + o_rw);
+                roi_weight_off = o_rw;
+                ga.rois = (RoiDev*)e->d_rois.p;
+                ga.max_rois = L->det_cap;
+                ga.group_max = (uint32_t)e->group_max;
+            }
             if ((rc = e->d_roi_units.ensure((size_t)e->roi_unit_cap * sizeof(RoiUnit)))) return rc;
             if ((rc = e->d_roi_det.ensure((size_t)e->roi_det_cap * sizeof(RoiDet)))) return rc;
             uint32_t* roi_counts = (uint32_t*)L->d_counts.p + CountsLayout::roi_off_u32;   // zeroed with the block by enqueue_cascade
@@ -1857,14 +1902,24 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
             ca.max_stage_nodes = pl2->max_stage_nodes;
             ca.stage_entered = (unsigned long long*)(roi_counts + 8);
             HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], e->stream));
-            const int hrc = launch_roi_chain(ra, ca, true, pl2->trees, count2, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
+            if (grouped) {
+                ga.n_rois = ra.n_rois;
+                const int grc = launch_group_rois(ga, e->stream);
+                if (grc) {
+                    set_error("grouping launch failed: %s", hipGetErrorString((hipError_t)grc));
+                    return VJ_ERR_HIP;
+                }
+                HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 5, ga.overflow, 4, hipMemcpyDeviceToHost, e->stream));
+            }
+            const int hrc = launch_roi_chain(ra, ca, !grouped, pl2->trees, count2, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
             if (hrc) {
                 set_error("region pass launch failed: %s", hipGetErrorString((hipError_t)hrc));
                 return VJ_ERR_HIP;
             }
             HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 1], e->stream));
             // the region counters join the block enqueue_cascade already copies; copy them again now that they are final
-            HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32, roi_counts, (8 + (size_t)VJ_MAX_STAGES * 2) * 4,
+            HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32, roi_counts, 5 * 4, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 8, roi_counts + 8, (size_t)VJ_MAX_STAGES * 2 * 4,
                                    hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipEventRecord(L->done, e->stream));
             HIP_TRY(hipEventSynchronize(L->done));
@@ -1882,6 +1937,19 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
                 if ((rc = L->d_det.ensure((size_t)want * sizeof(DetEntry)))) return rc;
                 L->det_cap = want;
                 continue;
+            }
+            if (grouped && hc[CountsLayout::roi_off_u32 + 5] != 0) {
+                // a frame with more raw candidates than the device kernel groups: the same result the long way round
+                // (group on the host, hand the regions back as a list)
+                vj_result_free(out_first);
+                vj_result_free(out_second);
+                if ((rc = vj_detect(e, first, frames, n_frames, p_first, out_first))) return rc;
+                std::vector<vj_roi> rois(out_first->count);
+                for (uint32_t i = 0; i < out_first->count; ++i) {
+                    const vj_rect& r = out_first->rects[i];
+                    rois[i] = vj_roi{r.frame, r.x, r.y, r.w, r.h};
+                }
+                return vj_detect_rois(e, second, frames, n_frames, rois.data(), (int)rois.size(), p_second, out_second);
             }
             if (n_units > e->roi_unit_cap || n_det2 > e->roi_det_cap) {
                 while (e->roi_unit_cap < n_units) e->roi_unit_cap *= 2;
@@ -1902,11 +1970,29 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
         // second cascade
         std::vector<RoiDet> raw2(n_det2);
         if (n_det2) HIP_TRY(hipMemcpy(raw2.data(), e->d_roi_det.p, (size_t)n_det2 * sizeof(RoiDet), hipMemcpyDeviceToHost));
+        std::vector<RoiDev> regions;
+        size_t base_g = grouped1.size();
+        if (grouped) {   // the first result is the region list itself
+            const uint32_t n_rois = ((const uint32_t*)L->h_pinned)[CountsLayout::roi_off_u32 + 0];
+            regions.resize(n_rois);
+            std::vector<uint32_t> weights(n_rois);
+            if (n_rois) {
+                HIP_TRY(hipMemcpy(regions.data(), e->d_rois.p, (size_t)n_rois * sizeof(RoiDev), hipMemcpyDeviceToHost));
+                HIP_TRY(hipMemcpy(weights.data(), (const char*)e->d_group.p + roi_weight_off, (size_t)n_rois * 4u, hipMemcpyDeviceToHost));
+            }
+            for (uint32_t i = 0; i < n_rois; ++i)
+                grouped1.push_back(vj_rect{regions[i].x, regions[i].y, regions[i].w, regions[i].h, (float)weights[i], regions[i].frame + f0, -1});
+        }
         for (const RoiDet& d : raw2) {
             const uint32_t f = (uint32_t)(d.off / fbytes);
             const uint32_t el = (uint32_t)((d.off - (uint64_t)f * fbytes) / 4u);
-            const RawDet& r1 = dets1[base1 + d.roi];
-            dets2.push_back(Det2{(int)(base1 + d.roi), d.slot, el % stride - r1.x, el / stride - r1.y});
+            if (grouped) {
+                const RoiDev& r1 = regions[d.roi];
+                dets2.push_back(Det2{(int)(base_g + d.roi), d.slot, el % stride - (uint32_t)r1.x, el / stride - (uint32_t)r1.y});
+            } else {
+                const RawDet& r1 = dets1[base1 + d.roi];
+                dets2.push_back(Det2{(int)(base1 + d.roi), d.slot, el % stride - r1.x, el / stride - r1.y});
+            }
         }
         out_second->timing.cascade_ms += ms_roi;
         out_second->timing.total_ms += ms_roi;
@@ -1917,14 +2003,27 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
         }
     }
     // the first result in its sorted order; regions are numbered by their position in it
-    std::vector<uint32_t> order(dets1.size());
-    for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
-    std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
-        return std::tie(dets1[a].frame, dets1[a].slot, dets1[a].y, dets1[a].x) < std::tie(dets1[b].frame, dets1[b].slot, dets1[b].y, dets1[b].x);
-    });
-    std::vector<uint32_t> rank(dets1.size());
-    for (size_t i = 0; i < order.size(); ++i) rank[order[i]] = (uint32_t)i;
-    if ((rc = build_result(pl1, dets1, n_frames, *p_first, out_first))) return rc;
+    std::vector<uint32_t> rank;
+    if (grouped) {   // frames in order, groups in cv::partition's class order: already the result's order
+        rank.resize(grouped1.size());
+        for (size_t i = 0; i < rank.size(); ++i) rank[i] = (uint32_t)i;
+        out_first->count = (uint32_t)grouped1.size();
+        if (!grouped1.empty()) {
+            out_first->rects = (vj_rect*)malloc(grouped1.size() * sizeof(vj_rect));
+            if (!out_first->rects) return VJ_ERR_NOMEM;
+            memcpy(out_first->rects, grouped1.data(), grouped1.size() * sizeof(vj_rect));
+        }
+        fill_counters(pl1, n_frames, *p_first, out_first);
+    } else {
+        std::vector<uint32_t> order(dets1.size());
+        for (size_t i = 0; i < order.size(); ++i) order[i] = (uint32_t)i;
+        std::sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) {
+            return std::tie(dets1[a].frame, dets1[a].slot, dets1[a].y, dets1[a].x) < std::tie(dets1[b].frame, dets1[b].slot, dets1[b].y, dets1[b].x);
+        });
+        rank.resize(dets1.size());
+        for (size_t i = 0; i < order.size(); ++i) rank[order[i]] = (uint32_t)i;
+        if ((rc = build_result(pl1, dets1, n_frames, *p_first, out_first))) return rc;
+    }
     std::sort(dets2.begin(), dets2.end(), [&](const Det2& a, const Det2& b) {
         return std::make_tuple(rank[a.roi], a.slot, a.y, a.x) < std::make_tuple(rank[b.roi], b.slot, b.y, b.x);
     });

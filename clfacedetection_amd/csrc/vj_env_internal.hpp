@@ -167,6 +167,7 @@ struct vj_env {
     vj::DevBuf d_q[vj::MAX_PASSES];   // d_q[p]: windows waiting to enter pass p (p >= 1)
     vj::DevBuf d_skip_bits;           // P2 skip modes: visited-window bitmaps of the frames in flight
     vj::DevBuf d_rois, d_roi_units, d_roi_det;   // regions of interest on the device (vj_detect_chain)
+    vj::DevBuf d_group;                          // scratch of the device-side grouping (vj_detect_chain, min_neighbors != 0)
     uint32_t roi_unit_cap = 0, roi_det_cap = 0;
     typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t, uint32_t, uint32_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<vj::Plan>> plans;
@@ -194,6 +195,7 @@ struct vj_env {
     int tile_lds_nest = 1;        // LDS blocks of consecutive tile classes nest (k blocks of one = one block of the next)
     int tile_stage_x4 = 1;        // stage tile rows with 16-byte LDS-DMA loads (4x fewer texture-address instructions)
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales
+    int group_max = (int)vj::GROUP_MAX;   // vj_detect_chain groups up to this many raw candidates of one frame on the device (more: host path)
     int sp_tail_max = 48;         // global-gather sweeps switch to the stump-parallel tail when a wave holds at most this many windows (0: never)
     int gather_pairs = -1;        // global-gather sweeps evaluate two stumps per step, all their gathers in flight together: 0 never, 1 for
                                   // waves that hold a single chunk, 2 always, -1 = by batch size: 2 up to 4 frames (a single frame is bound

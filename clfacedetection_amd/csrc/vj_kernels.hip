@@ -48,8 +48,8 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Three launches per batch:
 //   1. band_colsum : per 8-row band, per column: sum and sum of squares (reads u8 once)
 //   2. band_scan   : per column, exclusive prefix of those over the bands
-//   3. band_rows   : one wave per band; per row: running column totals -> wave prefix
-//                    scan along x (__shfl_up) -> + carry of the chunks to the left.
+//   3. band_rows   : one wave per band; top edge = prefix along x of the column totals above, then
+//                    per row a wave prefix scan along x (DPP) + carry of the chunks to the left.
 // All integers, so the result is exact: sum wraps mod 2^32 like CV_32S, sqsum is u64.
 
 __device__ __forceinline__ uint32_t load_px4(const uint8_t* row, uint32_t x, uint32_t width) {
@@ -126,36 +126,74 @@ __global__ __launch_bounds__(256) void band_scan(IntegralArgs a) {
     uint32_t s = 0;
     uint64_t q = 0;
     size_t o = (size_t)frame * a.n_bands * a.band_pitch + x;
-    for (uint32_t b = 0; b < a.n_bands; ++b, o += a.band_pitch) {
-        const uint32_t ts = a.band_sum[o];
-        const uint32_t tq = a.band_sq[o];
-        a.band_sum[o] = s;         // exclusive prefix, in place
-        a.band_sq_prefix[o] = q;
-        s += ts;
-        q += tq;
+    // eight bands per step: the loads of a step are independent of its stores (the prefix is written in place)
+    for (uint32_t b0 = 0; b0 < a.n_bands; b0 += 8u) {
+        uint32_t ts[8], tq[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            const bool in = b0 + k < a.n_bands;
+            ts[k] = in ? a.band_sum[o + (size_t)k * a.band_pitch] : 0u;
+            tq[k] = in ? a.band_sq[o + (size_t)k * a.band_pitch] : 0u;
+        }
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            if (b0 + k < a.n_bands) {
+                a.band_sum[o + (size_t)k * a.band_pitch] = s;         // exclusive prefix, in place
+                a.band_sq_prefix[o + (size_t)k * a.band_pitch] = q;
+            }
+            s += ts[k];
+            q += tq[k];
+        }
+        o += (size_t)8u * a.band_pitch;
     }
 }
 
-__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint32_t t = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d) v += t;
-    }
+// Inclusive prefix sums over the 64 lanes with DPP adds only (no LDS crossbar traffic): shifts by 1, 2, 4, 8 inside
+// the rows of 16, then row_bcast15 / row_bcast31 carry the row totals on.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint32_t dpp_or_zero(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, ROW_MASK, 0xf, true);
+}
+__device__ __forceinline__ uint32_t wave_incl_scan(uint32_t v) {
+    v += dpp_or_zero<0x111, 0xf>(v);   // row_shr:1
+    v += dpp_or_zero<0x112, 0xf>(v);   // row_shr:2
+    v += dpp_or_zero<0x114, 0xf>(v);   // row_shr:4
+    v += dpp_or_zero<0x118, 0xf>(v);   // row_shr:8
+    v += dpp_or_zero<0x142, 0xa>(v);   // row_bcast15 -> rows 1, 3
+    v += dpp_or_zero<0x143, 0xc>(v);   // row_bcast31 -> rows 2, 3
     return v;
 }
-__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v, uint32_t lane) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const uint64_t t = __shfl_up(v, d, 64);
-        if (lane >= (uint32_t)d) v += t;
-    }
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ uint64_t dpp_or_zero(uint64_t v) {
+    return (uint64_t)dpp_or_zero<CTRL, ROW_MASK>((uint32_t)v) | (uint64_t)dpp_or_zero<CTRL, ROW_MASK>((uint32_t)(v >> 32)) << 32;
+}
+__device__ __forceinline__ uint64_t wave_incl_scan(uint64_t v) {
+    v += dpp_or_zero<0x111, 0xf>(v);
+    v += dpp_or_zero<0x112, 0xf>(v);
+    v += dpp_or_zero<0x114, 0xf>(v);
+    v += dpp_or_zero<0x118, 0xf>(v);
+    v += dpp_or_zero<0x142, 0xa>(v);
+    v += dpp_or_zero<0x143, 0xc>(v);
     return v;
+}
+template <typename T>
+__device__ __forceinline__ T wave_last(T v);
+template <>
+__device__ __forceinline__ uint32_t wave_last(uint32_t v) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 63); }
+template <>
+__device__ __forceinline__ uint64_t wave_last(uint64_t v) {
+    return (uint64_t)wave_last((uint32_t)v) | (uint64_t)wave_last((uint32_t)(v >> 32)) << 32;
 }
 
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint64_t u64x2_unaligned __attribute__((ext_vector_type(2), aligned(8)));
 
+// One wave per band of 8 rows, walking it in chunks of 256 columns (4 per lane).  The integral at (y, x) is the
+// integral at the band's top edge — a prefix along x of the column totals above the band, scanned once per chunk —
+// plus the prefixes along x of the band's rows down to y.  A row's prefix of squares stays below 2^32 for rows of up
+// to 66051 pixels (Q = uint32_t: one 32-bit DPP scan per row and image); wider images scan in 64 bits.  All integer
+// arithmetic: the sum wraps mod 2^32 like CV_32S whatever the order of the additions, the squared sum is exact.
+template <typename Q>
 __global__ __launch_bounds__(256) void band_rows(IntegralArgs a) {
     const uint32_t lane = lane_id();
     const uint32_t band = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -174,44 +212,65 @@ __global__ __launch_bounds__(256) void band_rows(IntegralArgs a) {
             sqs[x] = 0ull;
         }
     }
-    uint32_t rs[BAND_ROWS];  // per row: total of everything left of the current chunk
-    uint64_t rq[BAND_ROWS];
+    uint32_t rs[BAND_ROWS];  // per row: total of the row left of the current chunk
+    Q rq[BAND_ROWS];
 #pragma unroll
     for (int r = 0; r < BAND_ROWS; ++r) {
         rs[r] = 0;
         rq[r] = 0;
     }
+    uint32_t top_s = 0;      // integral at the band's top edge, left of the current chunk
+    uint64_t top_q = 0;
     for (uint32_t x0 = 0; x0 < a.width; x0 += 256u) {
         const uint32_t x = x0 + lane * 4u;
         const bool in = x < a.width;
-        uint32_t cs[4] = {0, 0, 0, 0};
-        uint64_t cq[4] = {0, 0, 0, 0};
-        if (in) {  // running column totals start at the prefix over the bands above
+        uint32_t v[BAND_ROWS];
+#pragma unroll
+        for (int r = 0; r < BAND_ROWS; ++r)   // every row of the chunk is in flight before the first scan
+            v[r] = in && y0 + r < a.height ? load_gray4(img + (size_t)(y0 + r) * a.gray_stride, x, a.width, a.channels) : 0u;
+        uint32_t as[4] = {0, 0, 0, 0};   // running integral of the lane's four columns
+        uint64_t aq[4] = {0, 0, 0, 0};
+        if (in) {  // column totals above the band
             const uint4 t = *reinterpret_cast<const uint4*>(a.band_sum + bo + x);
-            cs[0] = t.x; cs[1] = t.y; cs[2] = t.z; cs[3] = t.w;
+            as[0] = t.x; as[1] = as[0] + t.y; as[2] = as[1] + t.z; as[3] = as[2] + t.w;
             const ulonglong2 u0 = *reinterpret_cast<const ulonglong2*>(a.band_sq_prefix + bo + x);
             const ulonglong2 u1 = *reinterpret_cast<const ulonglong2*>(a.band_sq_prefix + bo + x + 2);
-            cq[0] = u0.x; cq[1] = u0.y; cq[2] = u1.x; cq[3] = u1.y;
+            aq[0] = u0.x; aq[1] = aq[0] + u0.y; aq[2] = aq[1] + u1.x; aq[3] = aq[2] + u1.y;
+        }
+        {
+            const uint32_t is = wave_incl_scan(as[3]);
+            const uint64_t iq = wave_incl_scan(aq[3]);
+            const uint32_t base_s = top_s + (is - as[3]);
+            const uint64_t base_q = top_q + (iq - aq[3]);
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                as[c] += base_s;
+                aq[c] += base_q;
+            }
+            top_s += wave_last(is);
+            top_q += wave_last(iq);
         }
 #pragma unroll
         for (int r = 0; r < BAND_ROWS; ++r) {
             const uint32_t y = y0 + r;
             if (y < a.height) {  // uniform
-                const uint32_t v = in ? load_gray4(img + (size_t)y * a.gray_stride, x, a.width, a.channels) : 0u;
                 uint32_t ls[4];
-                uint64_t lq[4];
+                Q lq[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    const uint32_t p = (v >> (8 * c)) & 0xffu;
-                    cs[c] += p;
-                    cq[c] += (uint64_t)(p * p);
-                    ls[c] = cs[c] + (c ? ls[c - 1] : 0u);
-                    lq[c] = cq[c] + (c ? lq[c - 1] : 0ull);
+                    const uint32_t p = (v[r] >> (8 * c)) & 0xffu;
+                    ls[c] = p + (c ? ls[c - 1] : 0u);
+                    lq[c] = (Q)(p * p) + (c ? lq[c - 1] : (Q)0);
                 }
-                const uint32_t is = wave_incl_scan(ls[3], lane);
-                const uint64_t iq = wave_incl_scan(lq[3], lane);
+                const uint32_t is = wave_incl_scan(ls[3]);
+                const Q iq = wave_incl_scan(lq[3]);
                 const uint32_t base_s = rs[r] + (is - ls[3]);
-                const uint64_t base_q = rq[r] + (iq - lq[3]);
+                const Q base_q = rq[r] + (iq - lq[3]);
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    as[c] += base_s + ls[c];
+                    aq[c] += (uint64_t)(Q)(base_q + lq[c]);
+                }
                 const size_t ro = (size_t)(y + 1u) * ow;
                 if (x0 == 0 && lane == 0) {  // column 0 is zero
                     sum[ro] = 0u;
@@ -220,20 +279,19 @@ __global__ __launch_bounds__(256) void band_rows(IntegralArgs a) {
                 if (x + 4u <= a.width) {
                     // 16 (sum) and 32 (squared sum) contiguous bytes per lane: the wave writes
                     // contiguous 1 KiB / 2 KiB runs; rows are only 4-byte aligned (odd stride)
-                    *reinterpret_cast<u32x4_unaligned*>(sum + ro + x + 1u) =
-                        u32x4_unaligned{base_s + ls[0], base_s + ls[1], base_s + ls[2], base_s + ls[3]};
-                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 1u) = u64x2_unaligned{base_q + lq[0], base_q + lq[1]};
-                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 3u) = u64x2_unaligned{base_q + lq[2], base_q + lq[3]};
+                    *reinterpret_cast<u32x4_unaligned*>(sum + ro + x + 1u) = u32x4_unaligned{as[0], as[1], as[2], as[3]};
+                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 1u) = u64x2_unaligned{aq[0], aq[1]};
+                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 3u) = u64x2_unaligned{aq[2], aq[3]};
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
                         if (x + c < a.width) {
-                            sum[ro + x + c + 1u] = base_s + ls[c];
-                            sqs[ro + x + c + 1u] = base_q + lq[c];
+                            sum[ro + x + c + 1u] = as[c];
+                            sqs[ro + x + c + 1u] = aq[c];
                         }
                 }
-                rs[r] += __shfl(is, 63, 64);
-                rq[r] += __shfl(iq, 63, 64);
+                rs[r] += wave_last(is);
+                rq[r] += wave_last(iq);
             }
         }
     }
@@ -247,7 +305,8 @@ int launch_integral(const IntegralArgs& a, void* stream_) {
     dim3 g2((a.band_pitch + 255u) / 256u, a.n_frames, 1);
     hipLaunchKernelGGL(band_scan, g2, dim3(256), 0, stream, a);
     dim3 g3((a.n_bands + 3u) / 4u, a.n_frames, 1);
-    hipLaunchKernelGGL(band_rows, g3, dim3(256), 0, stream, a);
+    if ((uint64_t)a.width * 65025ull < (1ull << 32)) hipLaunchKernelGGL(band_rows<uint32_t>, g3, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(band_rows<uint64_t>, g3, dim3(256), 0, stream, a);
     return (int)hipGetLastError();
 }
 

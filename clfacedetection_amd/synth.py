@@ -7,6 +7,9 @@ its (kind, seed, size) alone; nothing is stored.  Kinds:
   smooth  128 + 60 sin(.05x) cos(.07y) + 40 sin(.013(x+y)) + noise in [-8, 8], clamped
   blocks  piecewise-constant 16x16 blocks of uniform bytes + noise in [-8, 8]
            (large flat regions: variance ~0, exercises the sqrt / "variance = 1" branch)
+  faces   the smooth background with a few crude frontal faces drawn on it (dark hair and eye band, darker eyes,
+           bright nose bridge and cheeks, dark mouth) at hashed positions and sizes: the frontal-face cascades answer
+           each with a CLUSTER of overlapping candidates — what grouping (min_neighbors) and the face -> eye chain need
 """
 from __future__ import annotations
 
@@ -40,7 +43,34 @@ def frame(kind: str, seed: int, height: int, width: int) -> np.ndarray:
         b = (_hash_u32(seed ^ 0x5BD1E995, by * bx) & np.uint32(0xFF)).astype(np.int32).reshape(by, bx)
         base = np.kron(b, np.ones((16, 16), np.int32))[:height, :width]
         return np.clip(base + jitter, 0, 255).astype(np.uint8)
+    if kind == "faces":
+        img = frame("smooth", seed, height, width).astype(np.int32)
+        h = _hash_u32(seed ^ 0x2545F491, 64)
+        lo, hi = 40, max(41, min(height, width) // 3)
+        for k in range(3 + int(h[0] % 6)):
+            s = lo + int(h[1 + 3 * k] % (hi - lo))
+            if s + 2 > height or s + 2 > width:
+                continue
+            x0, y0 = int(h[2 + 3 * k] % (width - s)), int(h[3 + 3 * k] % (height - s))
+            img[y0:y0 + s, x0:x0 + s] = crude_face(s) + jitter[y0:y0 + s, x0:x0 + s] // 2
+        return np.clip(img, 0, 255).astype(np.uint8)
     raise ValueError(f"unknown kind {kind!r}")
+
+
+def crude_face(s: int) -> np.ndarray:
+    """s x s gray levels of a schematic frontal face (int32); comparisons of exact quotients only."""
+    f = np.full((s, s), 200, np.int32)
+    yy, xx = np.mgrid[0:s, 0:s] / float(s)
+    f[yy < 0.18] = 90                                                              # hair
+    f[(yy > 0.28) & (yy < 0.42)] = 120                                             # eye band
+    for cx in (0.3, 0.7):
+        f[((xx - cx) / 0.11) ** 2 + ((yy - 0.35) / 0.06) ** 2 < 1] = 40            # eyes
+    f[(yy > 0.28) & (yy < 0.62) & (abs(xx - 0.5) < 0.07)] = 225                    # nose bridge
+    f[(yy > 0.42) & (yy < 0.62) & (abs(xx - 0.5) > 0.12) & (abs(xx - 0.5) < 0.38)] = 215   # cheeks
+    f[((xx - 0.5) / 0.2) ** 2 + ((yy - 0.76) / 0.05) ** 2 < 1] = 80                # mouth
+    f[(xx < 0.08) | (xx > 0.92)] = 100
+    f[yy > 0.92] = 110
+    return f
 
 
 def batch(n: int, height: int, width: int, seed0: int = 1, kinds=("noise", "smooth", "blocks")) -> np.ndarray:

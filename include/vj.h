@@ -179,7 +179,8 @@ int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
  * "tile_sp_begin", "tile_sp_max", "tile_ws_min", "tile_ws_max" = finish
  * thresholds, "tile_deinterleave", "tile_min_lanes", "max_subbatch", "det_cap", "gather_pairs" (stumps per step of the
  * global-gather sweeps: 0 one, 1 two for thin waves, 2 two always, -1 by batch size), "sp_tail_max" (a wave of the gather
- * sweeps with at most this many windows left finishes stump-parallel; 0 never), "seg_cut2", "plan_cache_max".
+ * sweeps with at most this many windows left finishes stump-parallel; 0 never), "seg_cut2", "plan_cache_max", "group_max"
+ * (vj_detect_chain: raw candidates of one frame grouped on the device, <= 2048; a frame with more takes the host path).
  * Unknown keys return VJ_ERR_ARG.                                               */
 int  vj_env_configure(vj_env* e, const char* key, const char* value);
 
@@ -304,13 +305,15 @@ int  vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int 
                     const vj_roi* rois, int n_rois, const vj_params* p, vj_result* out);
 
 /* Two cascades back to back with the hand-off on the device (BASELINE config 5): `first`
- * runs on the frames as vj_detect does; every raw candidate it finds becomes a region of interest in a
- * DEVICE-resident list (built by a kernel from the detection buffer), and `second` runs on those regions
- * reading the frames' integral images in place — rectangle sums over a region do not depend on where the
- * integral image starts, so the result equals running `second` on the sub-image (vj_detect_rois) — before
- * anything returns to the host.  out_first: as vj_detect (p_first->min_neighbors must be 0).  out_second:
- * rect.frame = index of the region in out_first->rects, x / y relative to the region's origin.
- * `second` must be a linear cascade (stumps or trees).                                                */
+ * runs on the frames as vj_detect does; what it finds becomes a DEVICE-resident list of regions of interest
+ * (built by kernels from the detection buffer), and `second` runs on those regions reading the frames'
+ * integral images in place — rectangle sums over a region do not depend on where the integral image starts,
+ * so the result equals running `second` on the sub-image (vj_detect_rois) — before anything returns to the
+ * host.  p_first->min_neighbors == 0: every raw candidate is a region.  != 0: the candidates are grouped ON
+ * THE DEVICE (cv::groupRectangles per frame, as vj_detect groups them on the host: same classes, same
+ * averages, same order) and the grouped faces are the regions.  out_first: as vj_detect with the same
+ * parameters.  out_second: rect.frame = index of the region in out_first->rects, x / y relative to the
+ * region's origin.  `second` must be a linear cascade (stumps or trees).                              */
 int  vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second, const vj_image* frames,
                      int n_frames, const vj_params* p_first, const vj_params* p_second, vj_result* out_first,
                      vj_result* out_second);

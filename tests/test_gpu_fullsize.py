@@ -89,3 +89,45 @@ def test_config5_256_frames_two_cascades(env, oracle, cascades):
         assert rows(r2.rects[r2.rects["frame"] == i]) == rows(ro)
     ro, _ = oracle.detect(face_a, frames[3])
     assert rows(r1.rects, 3) == rows(ro)
+
+
+def test_config5_256_frames_eyes_inside_grouped_faces(env, oracle, cascades):
+    """Config 5 as the reference's caller would run it: faces with minNeighbors 3, eyes inside every FACE.  Grouping on the
+    device equals grouping on the host at the full batch size; the chain on sub-batches gives the same; the second leg
+    equals the host hand-off and the oracle on sub-images."""
+    import torch
+    face, face_a = cascades("frontalface_alt2")
+    eye, eye_a = cascades("eye")
+    B, H, W = 256, 720, 1280
+    frames = synth.batch(B, H, W, seed0=5001, kinds=("faces", "noise", "smooth", "blocks"))
+    df = DeviceFrames.from_torch(torch.from_numpy(frames).cuda())
+    p1 = default_params(min_neighbors=3)
+    r1, r2 = env.detect_chain(face, eye, df, p1)
+    assert np.array_equal(env.detect(face, df, p1).rects, r1.rects)
+    assert len(r1.rects) >= 64 * 3 and len(r2.rects) > 0
+    n1 = 0
+    for k in range(0, B, 128):
+        a1, a2 = env.detect_chain(face, eye, frames[k:k + 128], p1)
+        b1 = a1.rects.copy()
+        b1["frame"] += k
+        assert np.array_equal(b1, r1.rects[(r1.rects["frame"] >= k) & (r1.rects["frame"] < k + 128)])
+        want2 = r2.rects[(r2.rects["frame"] >= n1) & (r2.rects["frame"] < n1 + len(a1.rects))].copy()
+        want2["frame"] -= n1
+        assert np.array_equal(a2.rects, want2)
+        n1 += len(a1.rects)
+    assert n1 == len(r1.rects)
+    sub = r1.rects[r1.rects["frame"] < 24]
+    rois = [(int(r["frame"]), int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"])) for r in sub]
+    host = env.detect_rois(eye, frames[:24], rois)
+    key = lambda rr: [tuple(int(r[k]) for k in ("frame", "scale_idx", "y", "x", "w", "h")) for r in rr]
+    assert key(r2.rects[r2.rects["frame"] < len(sub)]) == key(host.rects)
+    for i in range(0, len(rois), max(1, len(rois) // 6)):
+        f, x, y, w, h = rois[i]
+        ro, _ = oracle.detect(eye_a, np.ascontiguousarray(frames[f][y:y + h, x:x + w]))
+        assert rows(r2.rects[r2.rects["frame"] == i]) == rows(ro)
+    ro, _ = oracle.detect(face_a, frames[4])
+    xywh = np.stack([ro[k] for k in ("x", "y", "w", "h")], 1)
+    g, w = oracle.group_rectangles(xywh, 3)
+    mine = r1.rects[r1.rects["frame"] == 4]
+    assert [(int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"]), int(r["weight"])) for r in mine] == \
+           [(int(q[0]), int(q[1]), int(q[2]), int(q[3]), int(n)) for q, n in zip(g, w)]

@@ -30,6 +30,16 @@ def test_integral_shapes(env, oracle, h, w):
     assert np.array_equal(s, so) and np.array_equal(q, qo)
 
 
+def test_integral_very_wide_rows(env, oracle):
+    """Rows of more than 66051 pixels: a row's prefix of squares no longer fits 32 bits (band_rows<uint64_t>); bright
+    pixels so that it really overflows, and a height that is not a multiple of the band."""
+    img = np.full((11, 70001), 255, np.uint8)
+    img[::3, ::7] = make_frame("noise", 5, 11, 70001)[::3, ::7]
+    s, q = env.integral(img)
+    so, qo = oracle.integral(img)
+    assert int(qo[2, -1]) - int(qo[1, -1]) > 2**32 and np.array_equal(s, so) and np.array_equal(q, qo)
+
+
 def test_integral_strided_rows(env, oracle):
     big = make_frame("noise", 77, 200, 400)
     view = big[10:150, 37:300]           # row stride 400, unaligned start
