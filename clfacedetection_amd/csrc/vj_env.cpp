@@ -915,6 +915,7 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
             qa.q_in = (const QEntry*)e->d_q[ps].p;
             qa.q_in_count = d_qcount[ps];
             qa.q_ticket = d_qcount[0] + ps * Q_PARTS;   // queue 0 does not exist: its counters serve as tickets
+            qa.thin_pass_spread = e->thin_pass_spread ? 1u : 0u;
             qa.q_out = last ? nullptr : (QEntry*)e->d_q[ps + 1].p;
             qa.q_out_count = last ? nullptr : d_qcount[ps + 1];
             if (!pl->seg_fail.empty() && pl->seg_fail[ps] != 0) {   // stage tree: this segment's rejects continue
@@ -1108,6 +1109,12 @@ static int finish_batch(vj_env* e, Lane* L, Plan* pl, int f0, int W, int H, cons
             for (size_t l = 0; l < linfo.size(); ++l)
                 fprintf(stderr, "vj launch %zu kind %d class %d: max resident workgroups %llu\n", l, linfo[l].kind, linfo[l].lds_class,
                         se[(1 + l) * VJ_MAX_STAGES + 39]);
+            for (size_t l = 0; l < linfo.size(); ++l)   // queue passes: chunk time sum / max / chunks; stump-parallel tail: A, B, pairs, stages
+                if (linfo[l].kind == 1)
+                    fprintf(stderr, "vj queue launch %zu [%d,%d): chunks %llu sum %llu max %llu | tail A %llu B %llu pairs %llu stages %llu\n", l,
+                            linfo[l].stage_begin, linfo[l].stage_end, se[(1 + l) * VJ_MAX_STAGES + 50], se[(1 + l) * VJ_MAX_STAGES + 48],
+                            se[(1 + l) * VJ_MAX_STAGES + 49], se[(1 + l) * VJ_MAX_STAGES + 51], se[(1 + l) * VJ_MAX_STAGES + 52],
+                            se[(1 + l) * VJ_MAX_STAGES + 53], se[(1 + l) * VJ_MAX_STAGES + 54]);
             fprintf(stderr, "vj stamps:");
             for (int i = 40; i < 60; ++i) {
                 unsigned long long v = 0;
@@ -1391,6 +1398,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         e->tile_lds_nest = atoi(value) != 0;
         HIP_TRY(hipStreamSynchronize(e->stream));
         drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "thin_pass_spread") == 0) {
+        e->thin_pass_spread = atoi(value) != 0;
         return VJ_OK;
     }
     if (strcmp(key, "group_max") == 0) {

@@ -196,6 +196,7 @@ struct vj_env {
     int tile_stage_x4 = 1;        // stage tile rows with 16-byte LDS-DMA loads (4x fewer texture-address instructions)
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales
     int group_max = (int)vj::GROUP_MAX;   // vj_detect_chain groups up to this many raw candidates of one frame on the device (more: host path)
+    bool thin_pass_spread = true; // queue passes with fewer chunks than waves: only the first workgroups draw tickets
     int sp_tail_max = 48;         // global-gather sweeps switch to the stump-parallel tail when a wave holds at most this many windows (0: never)
     int gather_pairs = -1;        // global-gather sweeps evaluate two stumps per step, all their gathers in flight together: 0 never, 1 for
                                   // waves that hold a single chunk, 2 always, -1 = by batch size: 2 up to 4 frames (a single frame is bound

@@ -593,6 +593,7 @@ __device__ __forceinline__ uint32_t sweep_tail_stump_parallel(const CascadeArgs&
         const float threshold = stages[s].threshold;
         if (COUNT && lane == 0) atomicAdd(a.stage_entered + s, (unsigned long long)n);
         const uint32_t n_blocks = (n_nodes + 63u) >> 6;
+        const unsigned long long t_a = VJ_STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
         // A: verdict bits, lanes = stumps
         for (uint32_t b = 0; b < n_blocks; ++b) {
             const uint32_t j = b * 64u + lane;
@@ -611,6 +612,7 @@ __device__ __forceinline__ uint32_t sweep_tail_stump_parallel(const CascadeArgs&
             }
         }
         __builtin_amdgcn_wave_barrier();
+        const unsigned long long t_b = VJ_STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
         // B: lanes = windows; leaf values added in stump order
         const bool have = lane < n;
         const QEntry mine = q[have ? lane : 0u];
@@ -639,6 +641,13 @@ __device__ __forceinline__ uint32_t sweep_tail_stump_parallel(const CascadeArgs&
         const unsigned long long pm = __ballot(pass);
         __builtin_amdgcn_wave_barrier();   // every lane holds its entry and has read its masks
         if (pass) q[mbcnt(pm)] = mine;
+        if (VJ_STAMPS && lane == 0) {   // diagnostic build: verdict phase, leaf-sum phase, (window, block) pairs, stages
+            const unsigned long long t_e = __builtin_amdgcn_s_memtime();
+            atomicAdd(a.stage_entered + 51, t_b - t_a);
+            atomicAdd(a.stage_entered + 52, t_e - t_b);
+            atomicAdd(a.stage_entered + 53, (unsigned long long)n * n_blocks);
+            atomicAdd(a.stage_entered + 54, 1ull);
+        }
         n = (uint32_t)__popcll(pm);
         __builtin_amdgcn_wave_barrier();
     }
@@ -943,6 +952,18 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
         uint32_t total = 0;
         for (uint32_t i = 0; i < a.n_scales * Q_PARTS; ++i) total += counts[i];
         const uint32_t chunk = min((uint32_t)UNIT_WINDOWS, max(64u, ((total / a.total_waves + 63u) / 64u) * 64u));
+        if (a.thin_pass_spread != 0u) {
+            // Fewer chunks than waves (a late pass, a single frame): whichever waves draw the tickets first get the
+            // chunks, and with 24 resident waves per CU some CUs end up with twice the average — the pass then waits for
+            // the CU with the most (measured, 4096 x 4096 stage tree: 6.5 ms with 8 workgroups per CU against 3.9 ms
+            // with 4, same chunks).  Workgroups are dealt round-robin over XCDs and CUs
+            // (tools/microbench/dispatch_order.hip: the first 552 of 2048 sit 2-3 per CU on all 256 CUs), so only the
+            // first ceil(chunks / waves per workgroup) workgroups draw tickets; the others leave.  Speed only: the
+            // remaining waves loop until every part is drained.
+            uint32_t n_chunks = 0;
+            for (uint32_t i = 0; i < a.n_scales * Q_PARTS; ++i) n_chunks += (counts[i] + chunk - 1u) / chunk;
+            if (blockIdx.x >= max((n_chunks + WAVES_PER_BLOCK - 1u) / WAVES_PER_BLOCK, 1u)) return;
+        }
         uint32_t part = a.xcd_affinity != 0u ? (blockIdx.x & (Q_PARTS - 1u)) : 0u;
         for (uint32_t tries = 0; tries < Q_PARTS;) {
             uint32_t t = 0;
@@ -967,11 +988,18 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
             const uint32_t n = min(cnt - c0, chunk);
             for (uint32_t i = lane; i < n; i += 64u) q[i] = a.q_in[base + c0 + i];
             __builtin_amdgcn_wave_barrier();
+            const unsigned long long t_chunk = VJ_STAMPS ? __builtin_amdgcn_s_memtime() : 0ull;
             if (GENERAL)   // the rest of a stage tree, for the survivors of its linear prefix
                 run_stages_general<TREES, COUNT>(a, img, q, lds_tgt + wib * UNIT_WINDOWS, n, slot, scales[slot].table_first, lane);
             else
                 run_stages_linear<TREES, LAST, COUNT>(a, img, q, n, slot, scales[slot].table_first, q_base, lane, a.stage_begin, part);
             __builtin_amdgcn_wave_barrier();
+            if (VJ_STAMPS && lane == 0) {   // diagnostic build: time per chunk of a queue pass (sum, max, chunks)
+                const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_chunk;
+                atomicAdd(a.stage_entered + 48, dt);
+                atomicMax(a.stage_entered + 49, dt);
+                atomicAdd(a.stage_entered + 50, 1ull);
+            }
         }
     }
 }

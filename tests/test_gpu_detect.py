@@ -120,6 +120,10 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
             r = env.detect(c, frames, p)
             assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, b
         env.configure("blocks_per_cu", 8)
+        env.configure("thin_pass_spread", 0)       # every workgroup of a queue pass draws tickets / only the first ones do
+        r = env.detect(c, frames, p)
+        assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered
+        env.configure("thin_pass_spread", 1)
         for de, x4 in ((0, 1), (0, 0), (1, 0)):
             env.configure("tile_deinterleave", de)
             env.configure("tile_stage_x4", x4)
