@@ -42,6 +42,12 @@ MODE_CASES = [  # (id, cascade, generator, seed, height, width)
     ("m_eyeglasses_smooth", "eye_tree_eyeglasses", "smooth", 84, 240, 320),
 ]
 
+GROUP_CASES = [  # (id, first cascade, second cascade, seed, height, width, min_neighbors): drawn faces (synth kind "faces")
+    ("g_alt2_eye_3", "frontalface_alt2", "eye", 1, 360, 640, 3),
+    ("g_alt_eye_1", "frontalface_alt", "eye", 2, 300, 480, 1),
+    ("g_default_eye_3", "frontalface_default", "eye", 3, 360, 640, 3),
+]
+
 INTEGRAL_CASES = [  # (id, generator, seed, height, width)
     ("i_1x1", "noise", 1, 1, 1), ("i_3x5", "noise", 2, 3, 5), ("i_8x256", "noise", 3, 8, 256),
     ("i_9x257", "noise", 4, 9, 257), ("i_odd", "smooth", 5, 251, 333), ("i_vga", "noise", 6, 480, 640),

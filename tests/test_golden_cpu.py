@@ -70,3 +70,22 @@ def test_integral_wraps_like_cv32s(oracle):
     s, q = oracle.integral(img)
     assert int(s[-1, -1]) == (255 * 4200 * 4200) % (1 << 32)
     assert int(q[-1, -1]) == 255 * 255 * 4200 * 4200
+
+
+@pytest.mark.parametrize("g", json.load(open(os.path.join(G, "groups.json"))), ids=lambda d: d["id"])
+def test_group_fixture(oracle, cascades, g):
+    """Drawn faces -> candidates -> cv::groupRectangles -> second cascade inside every face: guards the `faces` generator,
+    the oracle's grouping and the fixture the GPU box checks vj_detect_chain against."""
+    _, a1 = cascades(g["first"])
+    _, a2 = cascades(g["second"])
+    img = make_frame("faces", g["seed"], g["height"], g["width"], oracle)
+    assert sha(img) == g["image_sha256"]
+    r, _ = oracle.detect(a1, img)
+    assert len(r) == g["raw_candidates"]
+    xywh = np.stack([r[k] for k in ("x", "y", "w", "h")], 1)
+    faces, wt = oracle.group_rectangles(xywh, max(g["min_neighbors"], 1))
+    assert [[int(v) for v in q] + [int(n)] for q, n in zip(faces, wt)] == g["faces"]
+    assert max(f[4] for f in g["faces"]) >= 10          # real clusters, not isolated candidates
+    x, y, w, h, _ = g["faces"][0]
+    r2, _ = oracle.detect(a2, np.ascontiguousarray(img[y:y + h, x:x + w]))
+    assert [[int(v) for v in (e["scale_idx"], e["x"], e["y"], e["w"], e["h"])] for e in r2] == g["inside"][0]

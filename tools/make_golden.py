@@ -81,3 +81,26 @@ for cid, casc, gen, seed, h, w in MODE_CASES:
     print(cid, {k: len(v["rects"]) for k, v in e.items() if isinstance(v, dict)})
 json.dump(modes, open(os.path.join(G, "modes.json"), "w"), indent=1)
 print("wrote", os.listdir(G))
+
+
+# faces -> grouped faces -> eyes inside them (vj_detect_chain with min_neighbors != 0): the oracle's candidates, its
+# restatement of cv::groupRectangles, and its candidates of the second cascade on every grouped face's sub-image
+from cases import GROUP_CASES  # noqa: E402
+groups = []
+for cid, c1, c2, seed, h, w, mn in GROUP_CASES:
+    a1 = load_vjc(os.path.join(DATA_DIR, f"haarcascade_{c1}.vjc"))
+    a2 = load_vjc(os.path.join(DATA_DIR, f"haarcascade_{c2}.vjc"))
+    img = make_frame("faces", seed, h, w, o)
+    r, _ = o.detect(a1, img)
+    xywh = np.stack([r[k] for k in ("x", "y", "w", "h")], 1) if len(r) else np.zeros((0, 4), np.int32)
+    g, wt = o.group_rectangles(xywh, max(mn, 1))
+    second = []
+    for q in g:
+        x, y, ww, hh = (int(v) for v in q)
+        r2, _ = o.detect(a2, np.ascontiguousarray(img[y:y + hh, x:x + ww]))
+        second.append([[int(v) for v in (e["scale_idx"], e["x"], e["y"], e["w"], e["h"])] for e in r2])
+    groups.append({"id": cid, "first": c1, "second": c2, "seed": seed, "height": h, "width": w, "min_neighbors": mn,
+                   "image_sha256": sha(img), "raw_candidates": len(r),
+                   "faces": [[int(v) for v in q] + [int(n)] for q, n in zip(g, wt)], "inside": second})
+    print(cid, len(r), len(g), sum(len(x) for x in second))
+json.dump(groups, open(os.path.join(G, "groups.json"), "w"), indent=1)
