@@ -1,0 +1,128 @@
+"""Randomized soak of the HIP path against the oracle — more cases than the test suite affords (run by hand on the GPU box:
+`python tests/soak_gpu.py [seconds] [first seed]`; not collected by pytest).  Every case draws a cascade, a frame kind
+and size, size limits, a scale factor, a mode (exhaustive grid, the CPU variants' skip sets, the OpenCV profile, the
+two-cascade chain with or without grouping), a batch size and a few tunables; rectangles and per-stage counts must equal
+the oracle's.  Prints one line per failure and a summary; exit code 1 if anything differed."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+try:
+    import torch  # noqa: F401  (first: see conftest.py)
+except Exception:
+    pass
+from cases import make_frame  # noqa: E402
+from clfacedetection_amd import (VJ_FLAG_COUNTERS, VJ_FLAG_SKIP_LIST, VJ_FLAG_SKIP_ROW, Cascade, Environment, default_params)  # noqa: E402
+from clfacedetection_amd.api import DATA_DIR  # noqa: E402
+from oracle.oracle import Oracle, load_vjc  # noqa: E402
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+o = Oracle()
+env = Environment(0)
+NAMES = ["frontalface_alt", "frontalface_default", "frontalface_alt2", "eye", "frontalface_alt_tree", "fullbody", "eye_tree_eyeglasses"]
+CASC = {n: (Cascade.load(n), load_vjc(os.path.join(DATA_DIR, f"haarcascade_{n}.vjc"))) for n in NAMES}
+TUNABLES = [("tile_split", ["0", "0.5", "1.3", "0,0.5,0.5"]), ("blocks_per_cu", ["1", "3", "8"]), ("gather_pairs", ["-1", "0", "2"]),
+            ("sp_tail_max", ["0", "16", "48"]), ("thin_pass_spread", ["0", "1"]), ("concurrent", ["0", "1"]),
+            ("tile_classes_kb", ["-2,-1,0", "0,0,0", "24,40,60"]), ("grid_block_w", ["0", "32"]), ("max_subbatch", ["0", "2"])]
+DEFAULTS = {"tile_split": "0,0.5,0.5", "blocks_per_cu": "8", "gather_pairs": "-1", "sp_tail_max": "48", "thin_pass_spread": "1",
+            "concurrent": "1", "tile_classes_kb": "-2,-1,0", "grid_block_w": "32", "max_subbatch": "0"}
+
+
+def rows(r):
+    return [tuple(int(q[k]) for k in ("scale_idx", "x", "y", "w", "h")) for q in r]
+
+
+t_end = time.time() + budget
+n_cases = n_fail = 0
+by_mode = {}
+seed = seed0
+while time.time() < t_end:
+    rng = np.random.default_rng(770000 + seed)
+    mode = ["grid", "grid", "grid", "skip_list", "skip_row", "opencv", "chain", "chain_grouped"][int(rng.integers(0, 8))]
+    name = NAMES[int(rng.integers(0, len(NAMES)))]
+    c, a = CASC[name]
+    linear = bool(np.all(a.stage_next == -1))
+    tilted = bool(a.node_tilted.any())
+    if tilted and mode != "opencv":
+        mode = "opencv"
+    if mode in ("skip_list", "skip_row") and not linear:
+        mode = "grid"
+    w = int(rng.integers(c.info.win_w + 11, 900))
+    h = int(rng.integers(c.info.win_h + 11, 600))
+    kind = ["noise", "smooth", "blocks", "faces"][int(rng.integers(0, 4))]
+    if kind == "faces" and min(h, w) < 130:
+        kind = "blocks"
+    img = make_frame(kind, 9000 + seed, h, w)
+    nb = int(rng.integers(1, 4))
+    tun = {}
+    for k, vals in TUNABLES:
+        if rng.random() < 0.3:
+            tun[k] = vals[int(rng.integers(0, len(vals)))]
+    for k, v in tun.items():
+        env.configure(k, v)
+    desc = (seed, mode, name, kind, h, w, nb, tun)
+    ok = True
+    try:
+        if mode in ("grid", "skip_list", "skip_row"):
+            mn = (0, 0) if rng.random() < 0.6 else (int(rng.integers(20, 70)),) * 2
+            mx = (0, 0) if rng.random() < 0.7 else (int(rng.integers(80, 300)),) * 2
+            sf = [1.1, 1.2, 1.05, 1.3, 1.5][int(rng.integers(0, 5))]
+            flags = VJ_FLAG_COUNTERS | {"grid": 0, "skip_list": VJ_FLAG_SKIP_LIST, "skip_row": VJ_FLAG_SKIP_ROW}[mode]
+            p = default_params(flags=flags, min_w=mn[0], min_h=mn[1], max_w=mx[0], max_h=mx[1], scale_factor=sf)
+            r = env.detect(c, [img] * nb if nb > 1 else img, p)
+            ro, st = o.detect(a, img, min_size=mn, max_size=mx, scale_factor=sf, mode={"grid": None, "skip_list": 2, "skip_row": 3}[mode])
+            for f in range(nb):
+                ok &= rows(r.rects[r.rects["frame"] == f]) == rows(ro)
+            ok &= r.stage_entered == [v * nb for v in st["stage_entered"]]
+            desc += (mn, mx, sf)
+        elif mode == "opencv":
+            sf = [1.1, 1.2, 1.3][int(rng.integers(0, 3))]
+            mn = (0, 0) if rng.random() < 0.7 else (int(rng.integers(24, 60)),) * 2
+            r = env.detect_opencv(c, [img] * nb if nb > 1 else img, min_size=mn, scale_factor=sf, flags=VJ_FLAG_COUNTERS)
+            ro, st = o.detect_opencvlike(a, img, min_size=mn, scale_factor=sf)
+            for f in range(nb):
+                ok &= sorted(rows(r.rects[r.rects["frame"] == f])) == sorted(rows(ro))
+            ok &= r.stage_entered == [v * nb for v in st["stage_entered"]] and r.windows == st["windows"] * nb
+            desc += (mn, sf)
+        else:
+            if not linear or name == "eye":
+                name = "frontalface_alt2"
+                c, a = CASC[name]
+            c2, a2 = CASC["eye"]
+            mnb = 0 if mode == "chain" else int(rng.integers(1, 4))
+            r1, r2 = env.detect_chain(c, c2, [img] * nb if nb > 1 else img, default_params(min_neighbors=mnb))
+            ro, _ = o.detect(a, img)
+            if mnb:
+                xywh = np.stack([ro[k] for k in ("x", "y", "w", "h")], 1) if len(ro) else np.zeros((0, 4), np.int32)
+                g, wt = o.group_rectangles(xywh, mnb)
+                want1 = [(int(q[0]), int(q[1]), int(q[2]), int(q[3]), int(n)) for q, n in zip(g, wt)]
+                got1 = [(int(q["x"]), int(q["y"]), int(q["w"]), int(q["h"]), int(q["weight"])) for q in r1.rects[r1.rects["frame"] == 0]]
+            else:
+                want1 = [(int(q["x"]), int(q["y"]), int(q["w"]), int(q["h"]), 0) for q in ro]
+                got1 = [(int(q["x"]), int(q["y"]), int(q["w"]), int(q["h"]), 0) for q in r1.rects[r1.rects["frame"] == 0]]
+            ok &= got1 == want1
+            for i, (x, y, ww, hh, _) in enumerate(want1[:6]):
+                r2o, _ = o.detect(a2, np.ascontiguousarray(img[y:y + hh, x:x + ww]))
+                ok &= rows(r2.rects[r2.rects["frame"] == i]) == rows(r2o)
+            desc += (mnb, len(want1))
+    except Exception as e:   # noqa: BLE001
+        ok = False
+        desc += (repr(e),)
+    for k in tun:
+        env.configure(k, DEFAULTS[k])
+    n_cases += 1
+    by_mode[mode] = by_mode.get(mode, 0) + 1
+    if not ok:
+        n_fail += 1
+        print("FAIL", desc, flush=True)
+    if n_cases % 25 == 0:
+        print(f"{n_cases} cases, {n_fail} failures, seed {seed}", flush=True)
+    seed += 1
+print(f"done: {n_cases} cases {by_mode}, {n_fail} failures, seeds {seed0}..{seed - 1}")
+sys.exit(1 if n_fail else 0)
