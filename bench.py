@@ -49,6 +49,7 @@ sys.path.insert(0, ROOT)
 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; L2 ~34.5 TB/s aggregate; LDS ~75 TB/s aggregate for ds_read_b32 gathers
 # (128 B/clk/CU x 256 CUs at ~2.4 GHz; b64 / b128 reads reach ~150 TB/s but a dword gather cannot use them)
 PEAK_GBPS = {"hbm": 8000.0, "l2": 34500.0, "lds": 75000.0}
+TA_GBPS = 256 * 64 * 4 / 49 * 2.1     # 2809: measured gather ceiling of the texture-address path (see below)
 KERNEL_OF = {"tile": ("vj::cascade_tile_pass<false, false, true>", "lds"),
              "block": ("vj::cascade_tile_pass<false, false, false>", "l2"),
              "grid": ("vj::cascade_pass<true, false, *, false, false>", "l2"),
@@ -240,6 +241,13 @@ def main() -> int:
                                 "algorithmic_bytes_per_launch": int(b // grp["n"]),
                                 "achieved": round(ach, 1), "peak": PEAK_GBPS[bound], "unit": "GB/s",
                                 "frac": round(ach / PEAK_GBPS[bound], 4)}
+            if bound == "l2":
+                # what really binds a global gather is the texture-address unit's rate for uncoalesced lanes, which depends on
+                # the lanes' stride: tools/microbench/ta_gather.hip (profiles/r01_ta_gather_microbench.log) measured 49 cycles
+                # per wave-load at a stride of 20 bytes (neighbouring windows at s = 5) and 77 for lanes random inside the L1
+                per_kernel[kind]["texture_address_rate"] = {
+                    "peak": TA_GBPS, "frac": round(ach / TA_GBPS, 4), "unit": "GB/s",
+                    "basis": "256 CUs x 64 lanes x 4 B / 49 cycles x 2.1 GHz: dword gathers at a lane stride of 20 B, measured"}
         int_ach = 13 * W * H * B / (integral_ms / K * 1e-3) / 1e9
         per_kernel["integral"] = {"kernel": "vj::band_colsum + vj::band_scan + vj::band_rows", "bound": "hbm", "launches_per_step": 3,
                                   "ms_per_step": round(integral_ms / K, 4), "algorithmic_bytes_per_launch": 13 * W * H * B,
