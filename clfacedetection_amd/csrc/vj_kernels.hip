@@ -405,6 +405,10 @@ __device__ __forceinline__ float node_rect_sum(const Img& img, const NodeRecDev&
 template <typename Img>
 __device__ __forceinline__ void node_rect_sum_pair(const Img& img, const NodeRecDev& ra, const NodeRecDev& rb, uint32_t off,
                                                    float& sum_a, float& sum_b);
+template <int NC, typename Img>
+__device__ __forceinline__ void stage_sum_tree2_multi(const Img& img, kptr<NodeRecDev> tab, uint32_t n_trees,
+                                                      const uint32_t (&off)[NC], const float (&var)[NC],
+                                                      float (&stage_sum)[NC]);   // (defined with the tile kernel's sweeps)
 
 // One stump-based stage on one window (clod.cl:49-82).  `tab` points at the stage's
 // first node record of the wave's scale; every table value is wave-uniform.  Two stumps per step: their 16 (24)
