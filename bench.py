@@ -246,7 +246,7 @@ def main() -> int:
                 # the lanes' stride: tools/microbench/ta_gather.hip (profiles/r01_ta_gather_microbench.log) measured 49 cycles
                 # per wave-load at a stride of 20 bytes (neighbouring windows at s = 5) and 77 for lanes random inside the L1
                 per_kernel[kind]["texture_address_rate"] = {
-                    "peak": TA_GBPS, "frac": round(ach / TA_GBPS, 4), "unit": "GB/s",
+                    "peak": round(TA_GBPS, 1), "frac": round(ach / TA_GBPS, 4), "unit": "GB/s",
                     "basis": "256 CUs x 64 lanes x 4 B / 49 cycles x 2.1 GHz: dword gathers at a lane stride of 20 B, measured"}
         int_ach = 13 * W * H * B / (integral_ms / K * 1e-3) / 1e9
         per_kernel["integral"] = {"kernel": "vj::band_colsum + vj::band_scan + vj::band_rows", "bound": "hbm", "launches_per_step": 3,
