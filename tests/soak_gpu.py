@@ -1,5 +1,5 @@
 """Randomized soak of the HIP path against the oracle — more cases than the test suite affords (run by hand on the GPU box:
-`python tests/soak_gpu.py [seconds] [first seed]`; not collected by pytest).  Every case draws a cascade, a frame kind
+`python tests/soak_gpu.py [seconds] [first seed] [max width] [max height]`; not collected by pytest).  Every case draws a cascade, a frame kind
 and size, size limits, a scale factor, a mode (exhaustive grid, the CPU variants' skip sets, the OpenCV profile, the
 two-cascade chain with or without grouping), a batch size and a few tunables; rectangles and per-stage counts must equal
 the oracle's.  Prints one line per failure and a summary; exit code 1 if anything differed."""
@@ -23,6 +23,8 @@ from oracle.oracle import Oracle, load_vjc  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 300.0
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+max_w = int(sys.argv[3]) if len(sys.argv) > 3 else 900      # frame sizes are drawn up to max_w x max_h
+max_h = int(sys.argv[4]) if len(sys.argv) > 4 else 600
 o = Oracle()
 env = Environment(0)
 NAMES = ["frontalface_alt", "frontalface_default", "frontalface_alt2", "eye", "frontalface_alt_tree", "fullbody", "eye_tree_eyeglasses"]
@@ -53,8 +55,8 @@ while time.time() < t_end:
         mode = "opencv"
     if mode in ("skip_list", "skip_row") and not linear:
         mode = "grid"
-    w = int(rng.integers(c.info.win_w + 11, 900))
-    h = int(rng.integers(c.info.win_h + 11, 600))
+    w = int(rng.integers(c.info.win_w + 11, max_w))
+    h = int(rng.integers(c.info.win_h + 11, max_h))
     kind = ["noise", "smooth", "blocks", "faces"][int(rng.integers(0, 4))]
     if kind == "faces" and min(h, w) < 130:
         kind = "blocks"
