@@ -6,7 +6,7 @@ from clfacedetection_amd import Cascade, Environment, synth
 env = Environment(0); c = Cascade.load("frontalface_alt")
 frames = synth.batch(6, 1080, 1920, seed0=1)
 for cfg in sys.argv[1:]:
-    for kv in cfg.split(","):
+    for kv in cfg.split(";"):
         env.configure(*kv.split("=", 1))
     for f in frames[:2]: env.detect(c, f)
     lat = []; tot = []; lm = None
