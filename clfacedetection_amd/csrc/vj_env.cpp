@@ -748,12 +748,14 @@ struct RawDet {
 
 // Where the counters of one batch live: [MAX_PASSES][MAX_SCALES][Q_PARTS] queue counts | det_count | pad | one
 // stage_entered[VJ_MAX_STAGES] (u64) array per kernel launch (array 0 is spare) | the counters of a region-of-interest
-// pass (vj_detect_chain): regions, units, invalid regions, unit ticket, detections, pad | its stage_entered array.
+// pass (vj_detect_chain): regions, units, invalid regions, unit ticket, detections, pad | its stage_entered array | the queue
+// counts of the tiles' own queue set (stage trees, enqueue_cascade).
 struct CountsLayout {
     static constexpr size_t q_counts = (size_t)MAX_SCALES * Q_PARTS;   // counters of one queue: [scale][part]
     static constexpr size_t stage_off_u32 = MAX_PASSES * q_counts + 2;
     static constexpr size_t roi_off_u32 = stage_off_u32 + (size_t)(1 + VJ_MAX_LAUNCHES) * VJ_MAX_STAGES * 2;
-    static constexpr size_t bytes = (roi_off_u32 + 8 + (size_t)VJ_MAX_STAGES * 2) * sizeof(uint32_t);
+    static constexpr size_t q2_off_u32 = roi_off_u32 + 8 + (size_t)VJ_MAX_STAGES * 2;   // second set of queue counters (stage trees)
+    static constexpr size_t bytes = (q2_off_u32 + MAX_PASSES * q_counts) * sizeof(uint32_t);
 };
 
 // Upload (or adopt) the frames of one batch and enqueue its integral images.  `copy_stream` != null: the upload runs
@@ -801,6 +803,8 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
     constexpr size_t q_counts = CountsLayout::q_counts;
     uint32_t* d_qcount[MAX_PASSES];
     for (int ps = 0; ps < MAX_PASSES; ++ps) d_qcount[ps] = (uint32_t*)L->d_counts.p + ps * q_counts;
+    uint32_t* d_qcount2[MAX_PASSES];   // the tiles' own queue set (stage trees: see split_sets below)
+    for (int ps = 0; ps < MAX_PASSES; ++ps) d_qcount2[ps] = (uint32_t*)L->d_counts.p + CountsLayout::q2_off_u32 + ps * q_counts;
     uint32_t* d_det_count = (uint32_t*)L->d_counts.p + MAX_PASSES * q_counts;
     unsigned long long* d_stage_entered = (unsigned long long*)((uint32_t*)L->d_counts.p + CountsLayout::stage_off_u32);
     const bool count = (p.flags & VJ_FLAG_COUNTERS) != 0;
@@ -905,22 +909,24 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
         };
         auto pass_is_last = [&](size_t ps) { return pl->seg_last.empty() ? ps + 1 == n_pass : pl->seg_last[ps] != 0; };
         const bool general_kernel = pl->general && pl->seg_last.empty();   // run_stages_general finishes the tree
-        auto queue_args = [&](size_t ps) {
+        auto queue_args = [&](size_t ps, int set = 0) {
             CascadeArgs qa = ca;
+            DevBuf* dq = set ? e->d_q2 : e->d_q;
+            uint32_t** qc = set ? d_qcount2 : d_qcount;
             qa.stage_begin = pl->pass_bounds[ps];
             qa.stage_end = pl->pass_bounds[ps + 1];
             const bool last = pass_is_last(ps);
             // pass ps reads queue ps (filled by pass ps-1 and by tiles that left at this boundary)
             // and appends its survivors to queue ps+1
-            qa.q_in = (const QEntry*)e->d_q[ps].p;
-            qa.q_in_count = d_qcount[ps];
-            qa.q_ticket = d_qcount[0] + ps * Q_PARTS;   // queue 0 does not exist: its counters serve as tickets
+            qa.q_in = (const QEntry*)dq[ps].p;
+            qa.q_in_count = qc[ps];
+            qa.q_ticket = qc[0] + ps * Q_PARTS;   // queue 0 does not exist: its counters serve as tickets
             qa.thin_pass_spread = e->thin_pass_spread ? 1u : 0u;
-            qa.q_out = last ? nullptr : (QEntry*)e->d_q[ps + 1].p;
-            qa.q_out_count = last ? nullptr : d_qcount[ps + 1];
+            qa.q_out = last ? nullptr : (QEntry*)dq[ps + 1].p;
+            qa.q_out_count = last ? nullptr : qc[ps + 1];
             if (!pl->seg_fail.empty() && pl->seg_fail[ps] != 0) {   // stage tree: this segment's rejects continue
-                qa.q_fail = (QEntry*)e->d_q[pl->seg_fail[ps]].p;
-                qa.q_fail_count = d_qcount[pl->seg_fail[ps]];
+                qa.q_fail = (QEntry*)dq[pl->seg_fail[ps]].p;
+                qa.q_fail_count = qc[pl->seg_fail[ps]];
             }
             return qa;
         };
@@ -938,6 +944,20 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
                 while (first_joint_pass < n_pass && pl->pass_bounds[first_joint_pass] < handover) ++first_joint_pass;
             const bool use_blocks = e->global_blocks && pl->n_block_units > 0 && pl->sp_pad != 0;
             const bool two_streams = e->concurrent && pl->block_first > 0 && ca.n_units > 0;
+            // Stage tree in chains (seg_last): the chains' queue passes would have to wait for BOTH the grid pass and the
+            // tiles, because a crowded tile hands its windows to the same queues — and the tiles take longer than the grid
+            // pass (4096 x 4096: 7.8 vs 4.8 ms, then 7.8 ms of queue passes).  So the tiles get a queue set of their own:
+            // the grid pass's survivors go down the tree on stream B while the tiles still run, and after the join the same
+            // passes run once more on what the tiles left (usually little: thin passes).
+            const bool split_sets = two_streams && pl->general && !pl->seg_last.empty() && e->tree_split_queues && !use_blocks;
+            if (split_sets) {
+                for (size_t ps = 1; ps < n_pass; ++ps) {
+                    if ((rc = e->d_q2[ps].ensure(e->d_q[ps].cap))) return rc;
+                    ca.q_pass[ps] = (QEntry*)e->d_q2[ps].p;        // (the grid and queue passes take theirs from queue_args)
+                    ca.q_pass_count[ps] = d_qcount2[ps];
+                }
+                first_joint_pass = n_pass;
+            }
             hipStream_t sB = two_streams ? e->stream2 : e->stream;
             if (two_streams) {
                 HIP_TRY(hipEventRecord(e->fork_ev, e->stream));
@@ -993,10 +1013,12 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
                 if ((rc = end_launch(sB))) return rc;
                 for (size_t ps = 1; ps < first_joint_pass && !hrc; ++ps) {
                     CascadeArgs qa = queue_args(ps);
-                    qa.total_waves = (uint32_t)b_blocks * WAVES_PER_BLOCK;
+                    // (next to the tiles one workgroup per CU; a stage tree's chains are latency-bound: all of them)
+                    const int qb = split_sets ? n_blocks : b_blocks;
+                    qa.total_waves = (uint32_t)qb * WAVES_PER_BLOCK;
                     if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, sB))) return rc;
                     qa.stage_entered = launch_counters();
-                    hrc = launch_cascade_pass(qa, false, pl->trees, pass_is_last(ps), count, false, b_blocks, sB);
+                    hrc = launch_cascade_pass(qa, false, pl->trees, pass_is_last(ps), count, false, qb, sB);
                     if ((rc = end_launch(sB))) return rc;
                 }
             } else {
@@ -1017,10 +1039,10 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
             }
             for (size_t ps = 1; ps < n_pass && ps < VJ_MAX_PASSES && ps <= first_joint_pass; ++ps)
                 HIP_TRY(hipEventRecord(L->pass_ev[ps], e->stream));
-            // joint passes
-            for (size_t ps = first_joint_pass; ps < n_pass && !hrc; ++ps) {
+            // joint passes (split_sets: all of them once more, on the tiles' queue set)
+            for (size_t ps = split_sets ? 1 : first_joint_pass; ps < n_pass && !hrc; ++ps) {
                 if (ps > first_joint_pass && ps < VJ_MAX_PASSES) HIP_TRY(hipEventRecord(L->pass_ev[ps], e->stream));
-                CascadeArgs qa = queue_args(ps);
+                CascadeArgs qa = queue_args(ps, split_sets ? 1 : 0);
                 if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, e->stream))) return rc;
                 qa.stage_entered = launch_counters();
                 hrc = launch_cascade_pass(qa, false, pl->trees, pass_is_last(ps), count, general_kernel, n_blocks, e->stream);
@@ -1306,6 +1328,7 @@ void vj_env_destroy(vj_env* e) {
         b->release();
     e->lane0.destroy();
     for (DevBuf& b : e->d_q) b.release();
+    for (DevBuf& b : e->d_q2) b.release();
     if (e->fork_ev) (void)hipEventDestroy(e->fork_ev);
     if (e->join_ev) (void)hipEventDestroy(e->join_ev);
     if (e->stream2) (void)hipStreamDestroy(e->stream2);
@@ -1398,6 +1421,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         e->tile_lds_nest = atoi(value) != 0;
         HIP_TRY(hipStreamSynchronize(e->stream));
         drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "tree_split_queues") == 0) {
+        e->tree_split_queues = atoi(value) != 0;
         return VJ_OK;
     }
     if (strcmp(key, "thin_pass_spread") == 0) {

@@ -165,6 +165,7 @@ struct vj_env {
     void *slack_sum = nullptr, *slack_sq = nullptr;
     // survivor queues + counters + detections
     vj::DevBuf d_q[vj::MAX_PASSES];   // d_q[p]: windows waiting to enter pass p (p >= 1)
+    vj::DevBuf d_q2[vj::MAX_PASSES];  // stage trees: the tiles' own queue set (enqueue_cascade: split_sets)
     vj::DevBuf d_skip_bits;           // P2 skip modes: visited-window bitmaps of the frames in flight
     vj::DevBuf d_rois, d_roi_units, d_roi_det;   // regions of interest on the device (vj_detect_chain)
     vj::DevBuf d_group;                          // scratch of the device-side grouping (vj_detect_chain, min_neighbors != 0)
@@ -196,6 +197,7 @@ struct vj_env {
     int tile_stage_x4 = 1;        // stage tile rows with 16-byte LDS-DMA loads (4x fewer texture-address instructions)
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales
     int group_max = (int)vj::GROUP_MAX;   // vj_detect_chain groups up to this many raw candidates of one frame on the device (more: host path)
+    bool tree_split_queues = true; // stage trees: the grid pass's survivors go down the tree while the tiles still run
     bool thin_pass_spread = true; // queue passes with fewer chunks than waves: only the first workgroups draw tickets
     int sp_tail_max = 48;         // global-gather sweeps switch to the stump-parallel tail when a wave holds at most this many windows (0: never)
     int gather_pairs = -1;        // global-gather sweeps evaluate two stumps per step, all their gathers in flight together: 0 never, 1 for

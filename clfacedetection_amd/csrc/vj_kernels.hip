@@ -953,8 +953,23 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
         // chunk size: spread this pass's windows over all waves (a wave works through its chunk serially, ~1 us
         // per stump, so late passes with few windows want small chunks), in whole 64-lane groups, at most the
         // LDS queue capacity
+        // (the counters are summed lane-parallel: a scalar walk over up to 512 of them is ~0.1 ms of latency, which
+        // was the floor of every queue pass launch)
+        constexpr uint32_t N_CNT = (MAX_SCALES * Q_PARTS + 63u) / 64u;
+        uint32_t my_cnt[N_CNT];
         uint32_t total = 0;
-        for (uint32_t i = 0; i < a.n_scales * Q_PARTS; ++i) total += counts[i];
+#pragma unroll
+        for (uint32_t k = 0; k < N_CNT; ++k) {
+            const uint32_t i = k * 64u + lane;
+            my_cnt[k] = i < a.n_scales * Q_PARTS ? a.q_in_count[i] : 0u;
+            total += my_cnt[k];
+        }
+        auto wave_total = [](uint32_t v) {
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+            return (uint32_t)__builtin_amdgcn_readfirstlane(v);
+        };
+        total = wave_total(total);
         const uint32_t chunk = min((uint32_t)UNIT_WINDOWS, max(64u, ((total / a.total_waves + 63u) / 64u) * 64u));
         if (a.thin_pass_spread != 0u) {
             // Fewer chunks than waves (a late pass, a single frame): whichever waves draw the tickets first get the
@@ -965,21 +980,34 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
             // first ceil(chunks / waves per workgroup) workgroups draw tickets; the others leave.  Speed only: the
             // remaining waves loop until every part is drained.
             uint32_t n_chunks = 0;
-            for (uint32_t i = 0; i < a.n_scales * Q_PARTS; ++i) n_chunks += (counts[i] + chunk - 1u) / chunk;
+#pragma unroll
+            for (uint32_t k = 0; k < N_CNT; ++k) n_chunks += (my_cnt[k] + chunk - 1u) / chunk;
+            n_chunks = wave_total(n_chunks);
             if (blockIdx.x >= max((n_chunks + WAVES_PER_BLOCK - 1u) / WAVES_PER_BLOCK, 1u)) return;
         }
+        // chunks per part (counter i belongs to part i % Q_PARTS, and 64 % Q_PARTS == 0: lane l sums part l % Q_PARTS):
+        // an empty or used-up part is left without walking its scales
+        uint32_t part_chunks_v = 0;
+#pragma unroll
+        for (uint32_t k = 0; k < N_CNT; ++k) part_chunks_v += (my_cnt[k] + chunk - 1u) / chunk;
+#pragma unroll
+        for (int d = 32; d >= (int)Q_PARTS; d >>= 1) part_chunks_v += __shfl_xor(part_chunks_v, d, 64);
         uint32_t part = a.xcd_affinity != 0u ? (blockIdx.x & (Q_PARTS - 1u)) : 0u;
         for (uint32_t tries = 0; tries < Q_PARTS;) {
-            uint32_t t = 0;
-            if (lane == 0) t = atomicAdd(a.q_ticket + part, 1u);
-            t = __builtin_amdgcn_readfirstlane(t);
-            // ticket -> (scale, chunk): walk the part's scales
-            uint32_t slot = 0, c = t;
-            for (; slot < a.n_scales; ++slot) {
-                const uint32_t n_chunks = (counts[slot * Q_PARTS + part] + chunk - 1u) / chunk;
-                if (c < n_chunks) break;
-                c -= n_chunks;
+            const uint32_t part_chunks = __builtin_amdgcn_readfirstlane((uint32_t)__shfl(part_chunks_v, (int)part, 64));   // (uniform: keep the walk scalar)
+            uint32_t t = part_chunks;
+            if (part_chunks != 0u) {
+                if (lane == 0) t = atomicAdd(a.q_ticket + part, 1u);
+                t = __builtin_amdgcn_readfirstlane(t);
             }
+            // ticket -> (scale, chunk): walk the part's scales
+            uint32_t slot = a.n_scales, c = t;
+            if (t < part_chunks)
+                for (slot = 0; slot < a.n_scales; ++slot) {
+                    const uint32_t n_chunks = (counts[slot * Q_PARTS + part] + chunk - 1u) / chunk;
+                    if (c < n_chunks) break;
+                    c -= n_chunks;
+                }
             if (slot == a.n_scales) {   // this part is used up: steal from the next one
                 part = (part + 1u) & (Q_PARTS - 1u);
                 ++tries;
