@@ -28,39 +28,14 @@ struct CvScaleHost {
     int win_w, win_h, end_x, end_y;
 };
 
-}  // namespace
-
-extern "C" {
-
-void vj_cv_params_default(vj_cv_params* p) {
-    if (!p) return;
-    memset(p, 0, sizeof(*p));
-    p->scale_factor = 1.1;
-}
-
-int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames, const vj_cv_params* p,
-                     vj_result* out) {
-    if (!e || !c || !p || !out || n_frames < 0 || (n_frames > 0 && !frames)) return VJ_ERR_ARG;
-    memset(out, 0, sizeof(*out));
-    if (n_frames == 0) return VJ_OK;
-    if (!(p->scale_factor > 1.0)) {
-        set_error("scale_factor must be > 1");
-        return VJ_ERR_ARG;
-    }
-    const int W = frames[0].width, H = frames[0].height;
-    if (W <= 0 || H <= 0 || W >= 65535 || H >= 65535) return VJ_ERR_ARG;
-    const int CH = image_channels(frames[0]);
-    for (int i = 0; i < n_frames; ++i)
-        if (!frames[i].data || frames[i].width != W || frames[i].height != H || image_channels(frames[i]) != CH ||
-            (CH != 1 && CH != 3 && CH != 4) || frames[i].stride < W * CH) {
-            set_error("frame %d: all frames of a batch must be non-null and of equal size and channel count", i);
-            return VJ_ERR_ARG;
-        }
+// Everything that depends on (cascade, frame size, parameters) only: scales, feature tables, stage records, row list.
+static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_cv_params* p, CvPlan* pl) {
     if ((int)c->stages.size() > VJ_MAX_STAGES || c->stages.empty()) {
         set_error("cascade has %zu stages; 1..%d are supported", c->stages.size(), VJ_MAX_STAGES);
         return VJ_ERR_LIMIT;
     }
-    const StageProgram prog = build_stage_program(*c);
+    pl->prog = build_stage_program(*c);
+    const StageProgram& prog = pl->prog;
     std::vector<uint32_t> order;
     if (!stage_sweep_order(prog, &order)) {
         set_error("stage links form a cycle");
@@ -72,6 +47,11 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
     for (const auto& t : c->trees)
         if (t.n_nodes != 1) trees = true;
     for (const auto& nd : c->nodes) has_tilted |= nd.tilted != 0;
+    pl->trees = trees;
+    pl->is_tree = is_tree;
+    pl->has_tilted = has_tilted;
+    pl->n_order = (uint32_t)order.size();
+    pl->n_stages = (uint32_t)c->stages.size();
     std::vector<uint8_t> two_rects(c->stages.size(), 1);
     for (size_t s2 = 0; s2 < c->stages.size(); ++s2)
         for (int t = 0; t < c->stages[s2].n_trees; ++t) {
@@ -82,8 +62,6 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 if (!(std::fabs((double)r2.weight) < 2.220446049250313e-16 || r2.w == 0 || r2.h == 0)) two_rects[s2] = 0;
             }
         }
-    HIP_TRY(hipSetDevice(e->device));
-
     // ---- the scale loop (tempcv.cpp:1344-1377)
     const uint32_t stride = (uint32_t)W + 1u;
     std::vector<CvScaleHost> hs;
@@ -107,7 +85,8 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
         }
     }
     const size_t n_nodes = c->nodes.size();
-    std::vector<CvScaleDev> scales(hs.size());
+    std::vector<CvScaleDev>& scales = pl->scales;
+    scales.assign(hs.size(), CvScaleDev{});
     std::vector<CvNodeRec> table(hs.size() * n_nodes);
     std::vector<UnitDev> rows;
     bool reach_ok = true;
@@ -218,22 +197,92 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
         return VJ_ERR_LIMIT;
     }
 
-    DevBuf d_table, d_scales, d_stages, d_rows, d_det, d_counts;
-    struct Releaser {
-        DevBuf* b[6];
-        ~Releaser() { for (DevBuf* x : b) x->release(); }
-    } releaser{{&d_table, &d_scales, &d_stages, &d_rows, &d_det, &d_counts}};
     int rc;
-    if ((rc = d_table.ensure(std::max<size_t>(table.size(), 1) * sizeof(CvNodeRec)))) return rc;
-    if ((rc = d_scales.ensure(std::max<size_t>(scales.size(), 1) * sizeof(CvScaleDev)))) return rc;
-    if ((rc = d_stages.ensure(stages.size() * sizeof(StageDev)))) return rc;
-    if ((rc = d_rows.ensure(std::max<size_t>(rows.size(), 1) * sizeof(UnitDev)))) return rc;
+    if ((rc = pl->d_table.ensure(std::max<size_t>(table.size(), 1) * sizeof(CvNodeRec)))) return rc;
+    if ((rc = pl->d_scales.ensure(std::max<size_t>(scales.size(), 1) * sizeof(CvScaleDev)))) return rc;
+    if ((rc = pl->d_stages.ensure(stages.size() * sizeof(StageDev)))) return rc;
+    if ((rc = pl->d_rows.ensure(std::max<size_t>(rows.size(), 1) * sizeof(UnitDev)))) return rc;
+    if (!table.empty()) HIP_TRY(hipMemcpy(pl->d_table.p, table.data(), table.size() * sizeof(CvNodeRec), hipMemcpyHostToDevice));
+    if (!scales.empty()) HIP_TRY(hipMemcpy(pl->d_scales.p, scales.data(), scales.size() * sizeof(CvScaleDev), hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(pl->d_stages.p, stages.data(), stages.size() * sizeof(StageDev), hipMemcpyHostToDevice));
+    if (!rows.empty()) HIP_TRY(hipMemcpy(pl->d_rows.p, rows.data(), rows.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
+    pl->n_rows = (uint32_t)rows.size();
+    return VJ_OK;
+}
+
+static int get_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_cv_params* p, CvPlan** out) {
+    uint64_t sf_bits;
+    memcpy(&sf_bits, &p->scale_factor, 8);
+    const vj_env::CvPlanKey key(c->uid, W, H, p->min_w, p->min_h, sf_bits);
+    auto it = e->cv_plans.find(key);
+    if (it != e->cv_plans.end()) {
+        it->second->last_used = ++e->plan_tick;
+        *out = it->second.get();
+        return VJ_OK;
+    }
+    if ((int)e->cv_plans.size() >= std::max(1, e->plan_cache_max)) {   // bounded: the least recently used plans go first
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        while ((int)e->cv_plans.size() >= std::max(1, e->plan_cache_max)) {
+            auto lru = e->cv_plans.begin();
+            for (auto i = e->cv_plans.begin(); i != e->cv_plans.end(); ++i)
+                if (i->second->last_used < lru->second->last_used) lru = i;
+            lru->second->release_device();
+            e->cv_plans.erase(lru);
+        }
+    }
+    auto pl = std::make_unique<CvPlan>();
+    const int rc = build_cv_plan(e, c, W, H, p, pl.get());
+    if (rc) {
+        pl->release_device();
+        return rc;
+    }
+    pl->last_used = ++e->plan_tick;
+    *out = pl.get();
+    e->cv_plans[key] = std::move(pl);
+    return VJ_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+void vj_cv_params_default(vj_cv_params* p) {
+    if (!p) return;
+    memset(p, 0, sizeof(*p));
+    p->scale_factor = 1.1;
+}
+
+int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames, const vj_cv_params* p,
+                     vj_result* out) {
+    if (!e || !c || !p || !out || n_frames < 0 || (n_frames > 0 && !frames)) return VJ_ERR_ARG;
+    memset(out, 0, sizeof(*out));
+    if (n_frames == 0) return VJ_OK;
+    if (!(p->scale_factor > 1.0)) {
+        set_error("scale_factor must be > 1");
+        return VJ_ERR_ARG;
+    }
+    const int W = frames[0].width, H = frames[0].height;
+    if (W <= 0 || H <= 0 || W >= 65535 || H >= 65535) return VJ_ERR_ARG;
+    const int CH = image_channels(frames[0]);
+    for (int i = 0; i < n_frames; ++i)
+        if (!frames[i].data || frames[i].width != W || frames[i].height != H || image_channels(frames[i]) != CH ||
+            (CH != 1 && CH != 3 && CH != 4) || frames[i].stride < W * CH) {
+            set_error("frame %d: all frames of a batch must be non-null and of equal size and channel count", i);
+            return VJ_ERR_ARG;
+        }
+    HIP_TRY(hipSetDevice(e->device));
+    CvPlan* pl;
+    int rc = get_cv_plan(e, c, W, H, p, &pl);
+    if (rc) return rc;
+    const std::vector<CvScaleDev>& scales = pl->scales;
+    const StageProgram& prog = pl->prog;
+    const bool trees = pl->trees, is_tree = pl->is_tree, has_tilted = pl->has_tilted;
+    const uint32_t stride = (uint32_t)W + 1u;
+    const uint32_t frame_elems = frame_elems_for(W, H);
+    DevBuf& d_det = e->d_cv_det;
+    DevBuf& d_counts = e->d_cv_counts;
     const size_t counts_bytes = 2 * VJ_MAX_STAGES * sizeof(uint64_t) + 16;
     if ((rc = d_counts.ensure(counts_bytes))) return rc;
-    if (!table.empty()) HIP_TRY(hipMemcpy(d_table.p, table.data(), table.size() * sizeof(CvNodeRec), hipMemcpyHostToDevice));
-    if (!scales.empty()) HIP_TRY(hipMemcpy(d_scales.p, scales.data(), scales.size() * sizeof(CvScaleDev), hipMemcpyHostToDevice));
-    HIP_TRY(hipMemcpy(d_stages.p, stages.data(), stages.size() * sizeof(StageDev), hipMemcpyHostToDevice));
-    if (!rows.empty()) HIP_TRY(hipMemcpy(d_rows.p, rows.data(), rows.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
 
     const bool count = (p->flags & VJ_FLAG_COUNTERS) != 0;
     const uint64_t frame_bytes = (uint64_t)frame_elems * 4u;
@@ -241,7 +290,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
     if (e->max_subbatch > 0) max_frames = std::min(max_frames, e->max_subbatch);
     uint32_t det_cap = 1u << 16;
     std::vector<vj_rect> all;
-    for (int f0 = 0; f0 < n_frames && !rows.empty(); f0 += max_frames) {
+    for (int f0 = 0; f0 < n_frames && pl->n_rows != 0; f0 += max_frames) {
         const int nf = std::min(max_frames, n_frames - f0);
         if ((rc = ensure_image_buffers(e, W, H, nf, true, CH))) return rc;
         const uint8_t* d_gray;
@@ -260,14 +309,14 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             a.sum = (const uint32_t*)e->d_sum.p;
             a.sqsum = (const uint64_t*)e->d_sqsum.p;
             a.tilted = has_tilted ? (const uint32_t*)e->d_tilted.p : nullptr;
-            a.n_order = (uint32_t)order.size();
-            a.table = (const uint32_t*)d_table.p;
-            a.scales = (const CvScaleDev*)d_scales.p;
-            a.stages = (const StageDev*)d_stages.p;
-            a.rows = (const UnitDev*)d_rows.p;
-            a.n_rows = (uint32_t)rows.size();
+            a.n_order = pl->n_order;
+            a.table = (const uint32_t*)pl->d_table.p;
+            a.scales = (const CvScaleDev*)pl->d_scales.p;
+            a.stages = (const StageDev*)pl->d_stages.p;
+            a.rows = (const UnitDev*)pl->d_rows.p;
+            a.n_rows = pl->n_rows;
             a.n_frames = (uint32_t)nf;
-            a.n_stages = (uint32_t)stages.size();
+            a.n_stages = pl->n_stages;
             a.frame_elems = frame_elems;
             a.stride = stride;
             a.sum_h = (uint32_t)H + 1u;
@@ -303,7 +352,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             out->timing.total_ms += ms_t;
             out->timing.n_cascade_launches = 1;
             if (count) {
-                for (size_t s = 0; s < stages.size(); ++s) out->counters.stage_entered[s] += h[s];
+                for (size_t s = 0; s < pl->n_stages; ++s) out->counters.stage_entered[s] += h[s];
                 out->counters.windows += h[VJ_MAX_STAGES];
             }
             std::vector<CvDet> raw(n_det);
@@ -330,7 +379,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
     if (count) {
         vj_counters& k = out->counters;
         uint64_t rect_evals = 0;
-        for (size_t s = 0; s < stages.size(); ++s) {
+        for (size_t s = 0; s < pl->n_stages; ++s) {
             k.stump_evals += k.stage_entered[s] * prog.n_nodes[s];
             rect_evals += k.stage_entered[s] * prog.n_rects[s];
         }

@@ -1324,7 +1324,7 @@ void vj_env_destroy(vj_env* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     drop_plans(e);
     for (DevBuf* b : {&e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_tilted, &e->d_out,
-                      &e->d_skip_bits, &e->d_rois, &e->d_roi_units, &e->d_roi_det, &e->d_group})
+                      &e->d_skip_bits, &e->d_rois, &e->d_roi_units, &e->d_roi_det, &e->d_group, &e->d_cv_det, &e->d_cv_counts})
         b->release();
     e->lane0.destroy();
     for (DevBuf& b : e->d_q) b.release();
@@ -1345,6 +1345,8 @@ int vj_env_device_name(const vj_env* e, char* buf, size_t cap) {
 static void drop_plans(vj_env* e) {
     for (auto& kv : e->plans) kv.second->release_device();
     e->plans.clear();
+    for (auto& kv : e->cv_plans) kv.second->release_device();
+    e->cv_plans.clear();
 }
 
 int vj_env_configure(vj_env* e, const char* key, const char* value) {

@@ -95,6 +95,20 @@ struct Plan {
     }
 };
 
+// What vj_detect_opencv derives from (cascade, frame size, parameters): kept per environment like the clod plans, so that a
+// caller that hands over one frame per call (main.cpp:145) does not rebuild and upload 42 feature tables every time.
+struct CvPlan {
+    std::vector<CvScaleDev> scales;   // host copy (window sizes and scale indices of the result)
+    StageProgram prog;
+    uint32_t n_stages = 0, n_order = 0, n_rows = 0;
+    bool trees = false, is_tree = false, has_tilted = false;
+    DevBuf d_table, d_scales, d_stages, d_rows;
+    uint64_t last_used = 0;
+    void release_device() {
+        for (DevBuf* b : {&d_table, &d_scales, &d_stages, &d_rows}) b->release();
+    }
+};
+
 }  // namespace vj
 
 namespace vj {
@@ -172,6 +186,9 @@ struct vj_env {
     uint32_t roi_unit_cap = 0, roi_det_cap = 0;
     typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t, uint32_t, uint32_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<vj::Plan>> plans;
+    typedef std::tuple<uint64_t, int, int, int, int, uint64_t> CvPlanKey;   // cascade uid, W, H, min size, bits of the scale factor
+    std::map<CvPlanKey, std::unique_ptr<vj::CvPlan>> cv_plans;
+    vj::DevBuf d_cv_det, d_cv_counts;   // vj_detect_opencv: detection list and counters
     uint64_t plan_tick = 0;
     int plan_cache_max = 48;      // plans kept per environment; the least recently used one is released beyond that
                                   // (a stream of ROI sizes — eyes inside faces of any size — would otherwise grow

@@ -172,3 +172,32 @@ def test_randomized_parity(env, oracle, cascades, seed):
     ro, st = oracle.detect_opencvlike(a, img, min_size=mn, scale_factor=sf)
     assert sorted(rows(r.rects)) == sorted(rows(ro)), (casc, w, h, mn, sf)
     assert r.windows == st["windows"] and r.stage_entered == st["stage_entered"]
+
+
+def test_plan_cache_of_the_profile(env, oracle, cascades):
+    """vj_detect_opencv keeps what it derives from (cascade, frame size, parameters) per environment: repeated calls give
+    the same rectangles, another size / scale factor / min size / cascade gets its own plan, the cache is bounded, and an
+    evicted plan is rebuilt."""
+    c, a = cascades("frontalface_alt")
+    c2, a2 = cascades("frontalface_alt2")
+    img = synth.frame("blocks", 5, 300, 400)
+    want, _ = oracle.detect_opencvlike(a, img)
+    for _ in range(3):
+        assert sorted(rows(env.detect_opencv(c, img).rects)) == sorted(rows(want))
+    w2, _ = oracle.detect_opencvlike(a, img, scale_factor=1.2)
+    assert sorted(rows(env.detect_opencv(c, img, scale_factor=1.2).rects)) == sorted(rows(w2))
+    w3, _ = oracle.detect_opencvlike(a, img, min_size=(40, 40))
+    assert sorted(rows(env.detect_opencv(c, img, min_size=(40, 40)).rects)) == sorted(rows(w3))
+    w4, _ = oracle.detect_opencvlike(a2, img)
+    assert sorted(rows(env.detect_opencv(c2, img).rects)) == sorted(rows(w4))
+    assert sorted(rows(env.detect_opencv(c, img).rects)) == sorted(rows(want))
+    env.configure("plan_cache_max", 4)
+    try:
+        for k in range(12):                                   # more sizes than the cache holds
+            sub = np.ascontiguousarray(img[:200 + 5 * k, :300 + 7 * k])
+            ws, _ = oracle.detect_opencvlike(a, sub)
+            assert sorted(rows(env.detect_opencv(c, sub).rects)) == sorted(rows(ws)), k
+        assert sorted(rows(env.detect_opencv(c, img).rects)) == sorted(rows(want))
+    finally:
+        env.configure("plan_cache_max", 48)
+
