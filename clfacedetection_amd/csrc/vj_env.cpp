@@ -1264,6 +1264,185 @@ static int check_frames(const vj_image* frames, int n_frames, int* W_, int* H_, 
 
 static void drop_plans(vj_env* e);
 
+// Arguments of the region pass (roi_plan_units + cascade_roi_pass): `second` inside regions of the nf frames whose integral
+// images sit in e->d_sum / e->d_sqsum.  The region list is e->d_rois (max_rois entries), its length on the device at
+// roi_counts[0]; the counters live in the lane's counts block.
+static void fill_region_args(vj_env* e, Lane* L, Plan* pl2, const vj_cascade* second, const vj_params& p_second, int W, int H, int nf,
+                             uint32_t max_rois, RoiArgs* ra_, CascadeArgs* ca_) {
+    uint32_t* roi_counts = (uint32_t*)L->d_counts.p + CountsLayout::roi_off_u32;
+    const uint32_t stride = (uint32_t)W + 1u;
+    RoiArgs& ra = *ra_;
+    memset(&ra, 0, sizeof(ra));
+    ra.frame_bytes = pl2->frame_elems * 4u;
+    ra.stride = stride;
+    ra.rois = (RoiDev*)e->d_rois.p;
+    ra.n_rois = roi_counts + 0;
+    ra.max_rois = max_rois;
+    ra.n_frames = (uint32_t)nf;
+    ra.frame_w = W;
+    ra.frame_h = H;
+    ra.win_w0 = second->win_w;
+    ra.win_h0 = second->win_h;
+    ra.units = (RoiUnit*)e->d_roi_units.p;
+    ra.n_units = roi_counts + 1;   // (+2: invalid regions)
+    ra.max_units = e->roi_unit_cap;
+    ra.ticket = roi_counts + 3;
+    ra.det = (RoiDet*)e->d_roi_det.p;
+    ra.det_count = roi_counts + 4;
+    ra.det_cap = e->roi_det_cap;
+    CascadeArgs& ca = *ca_;
+    memset(&ca, 0, sizeof(ca));
+    ca.sum = (const uint32_t*)e->d_sum.p;
+    ca.sqsum = (const uint64_t*)e->d_sqsum.p;
+    ca.table = (const uint32_t*)pl2->d_table.p;
+    ca.scales = (const ScaleDev*)pl2->d_scales.p;
+    ca.stages = (const StageDev*)pl2->d_stages.p;
+    ca.n_frames = (uint32_t)nf;
+    ca.n_scales = (uint32_t)pl2->scales.size();
+    ca.frame_elems = pl2->frame_elems;
+    ca.sum_bytes = (uint32_t)((uint64_t)pl2->frame_elems * 4u * (uint64_t)nf);
+    ca.stride = stride;
+    ca.stage_begin = 0;
+    ca.stage_end = (uint32_t)pl2->stages.size();
+    ca.identity_order = 1u;
+    ca.tree2 = 0u;
+    ca.signed_mean = (p_second.flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
+    ca.gather_pairs = 2u;   // regions are small: thin waves, latency-bound
+    ca.sp_tail_max = (uint32_t)std::max(0, std::min(e->sp_tail_max, 48));
+    ca.max_stage_nodes = pl2->max_stage_nodes;
+    ca.stage_entered = (unsigned long long*)(roi_counts + 8);
+}
+
+// vj_detect_rois on frames of one size with a linear cascade: one integral per frame and ONE region pass for regions of
+// any sizes (the machinery of vj_detect_chain's second half, the region list uploaded instead of built on the device) —
+// not one plan and one vj_detect call per distinct region size.
+static int detect_rois_on_device(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames, const vj_roi* rois, int n_rois,
+                                 const vj_params* p, int W, int H, vj_result* out) {
+    int rc;
+    Plan* pl2;
+    if ((rc = get_plan(e, c, W, H, *p, &pl2))) return rc;
+    const uint64_t max_frames = max_frames_per_subbatch(e, pl2);
+    if (max_frames == 0) {
+        set_error("a single frame exceeds the 32-bit offset range");
+        return VJ_ERR_LIMIT;
+    }
+    {
+        uint64_t dummy = 0;
+        if (pl2->frames_q == 0 && (rc = layout_queues(pl2, 1, &dummy))) return rc;
+    }
+    Lane* L = &e->lane0;
+    const bool count2 = (p->flags & VJ_FLAG_COUNTERS) != 0;
+    const uint32_t stride = (uint32_t)W + 1u;
+    const uint64_t fbytes = (uint64_t)pl2->frame_elems * 4u;
+    struct Det2 { int roi; uint32_t slot, x, y; };
+    std::vector<Det2> dets2;
+    for (int f0 = 0; f0 < n_frames; f0 += (int)max_frames) {
+        const int nf = (int)std::min<uint64_t>(max_frames, (uint64_t)(n_frames - f0));
+        std::vector<RoiDev> regions;
+        std::vector<int> index;   // position in `regions` -> the caller's region
+        for (int i = 0; i < n_rois; ++i)
+            if (rois[i].frame >= f0 && rois[i].frame < f0 + nf) {
+                regions.push_back(RoiDev{rois[i].frame - f0, rois[i].x, rois[i].y, rois[i].w, rois[i].h});
+                index.push_back(i);
+            }
+        if (regions.empty()) continue;
+        if ((rc = enqueue_prepare(e, L, pl2, frames + f0, nf, W, H, false, nullptr))) return rc;
+        if (e->roi_unit_cap == 0) e->roi_unit_cap = 1u << 18;
+        if (e->roi_det_cap == 0) e->roi_det_cap = 1u << 16;
+        const uint32_t n_reg = (uint32_t)regions.size();
+        if ((rc = e->d_rois.ensure((size_t)n_reg * sizeof(RoiDev)))) return rc;
+        HIP_TRY(hipMemcpyAsync(e->d_rois.p, regions.data(), (size_t)n_reg * sizeof(RoiDev), hipMemcpyHostToDevice, e->stream));
+        uint32_t n_units = 0, n_det2 = 0;
+        float ms_roi = 0;
+        bool ok = false;
+        for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
+            if ((rc = e->d_roi_units.ensure((size_t)e->roi_unit_cap * sizeof(RoiUnit)))) return rc;
+            if ((rc = e->d_roi_det.ensure((size_t)e->roi_det_cap * sizeof(RoiDet)))) return rc;
+            uint32_t* roi_counts = (uint32_t*)L->d_counts.p + CountsLayout::roi_off_u32;
+            HIP_TRY(hipMemsetAsync(roi_counts, 0, (8 + (size_t)VJ_MAX_STAGES * 2) * 4, e->stream));
+            HIP_TRY(hipMemcpyAsync(roi_counts, &n_reg, 4, hipMemcpyHostToDevice, e->stream));
+            RoiArgs ra;
+            CascadeArgs ca;
+            fill_region_args(e, L, pl2, c, *p, W, H, nf, n_reg, &ra, &ca);
+            HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], e->stream));
+            const int hrc = launch_roi_chain(ra, ca, false, pl2->trees, count2, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
+            if (hrc) {
+                set_error("region pass launch failed: %s", hipGetErrorString((hipError_t)hrc));
+                return VJ_ERR_HIP;
+            }
+            HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 1], e->stream));
+            HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32, roi_counts, (8 + (size_t)VJ_MAX_STAGES * 2) * 4,
+                                   hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipEventRecord(L->done, e->stream));
+            HIP_TRY(hipEventSynchronize(L->done));
+            const uint32_t* hc = (const uint32_t*)L->h_pinned;
+            n_units = hc[CountsLayout::roi_off_u32 + 1];
+            n_det2 = hc[CountsLayout::roi_off_u32 + 4];
+            if (hc[CountsLayout::roi_off_u32 + 2] != 0) {
+                set_error("internal error: %u regions outside their frames", hc[CountsLayout::roi_off_u32 + 2]);
+                return VJ_ERR_HIP;
+            }
+            if (n_units > e->roi_unit_cap || n_det2 > e->roi_det_cap) {
+                while (e->roi_unit_cap < n_units) e->roi_unit_cap *= 2;
+                while (e->roi_det_cap < n_det2) e->roi_det_cap *= 2;
+                continue;
+            }
+            HIP_TRY(hipEventElapsedTime(&ms_roi, L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], L->launch_ev[2 * VJ_MAX_LAUNCHES - 1]));
+            ok = true;
+        }
+        if (!ok) {
+            set_error("region buffers kept overflowing");
+            return VJ_ERR_LIMIT;
+        }
+        float ms_i = 0;
+        HIP_TRY(hipEventElapsedTime(&ms_i, L->ev[0], L->ev[1]));
+        out->timing.integral_ms += ms_i;
+        out->timing.cascade_ms += ms_roi;
+        out->timing.total_ms += ms_i + ms_roi;
+        out->timing.n_cascade_launches = 1;
+        std::vector<RoiDet> raw2(n_det2);
+        if (n_det2) HIP_TRY(hipMemcpy(raw2.data(), e->d_roi_det.p, (size_t)n_det2 * sizeof(RoiDet), hipMemcpyDeviceToHost));
+        for (const RoiDet& d : raw2) {
+            const uint32_t f = (uint32_t)(d.off / fbytes);
+            const uint32_t el = (uint32_t)((d.off - (uint64_t)f * fbytes) / 4u);
+            const RoiDev& r1 = regions[d.roi];
+            dets2.push_back(Det2{index[d.roi], d.slot, el % stride - (uint32_t)r1.x, el / stride - (uint32_t)r1.y});
+        }
+        if (count2) {
+            const unsigned long long* se = (const unsigned long long*)((const uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 8);
+            for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) out->counters.stage_entered[s2] += se[s2];
+        }
+    }
+    std::sort(dets2.begin(), dets2.end(), [](const Det2& a, const Det2& b) {
+        return std::make_tuple(a.roi, a.slot, a.y, a.x) < std::make_tuple(b.roi, b.slot, b.y, b.x);
+    });
+    out->count = (uint32_t)dets2.size();
+    if (!dets2.empty()) {
+        out->rects = (vj_rect*)malloc(dets2.size() * sizeof(vj_rect));
+        if (!out->rects) return VJ_ERR_NOMEM;
+        for (size_t i = 0; i < dets2.size(); ++i) {
+            const vj_scale_info& si = pl2->scales_info[dets2[i].slot];
+            out->rects[i] = vj_rect{(int32_t)dets2[i].x, (int32_t)dets2[i].y, si.win_w, si.win_h, 0.0f, dets2[i].roi, si.scale_idx};
+        }
+    }
+    if (p->min_neighbors != 0 && out->count) {
+        rc = vj_group_rectangles(out->rects, &out->count, (int)std::max<uint32_t>(p->min_neighbors, 1u), 0.2);
+        if (rc) return rc;
+    }
+    if (count2) {
+        vj_counters& k = out->counters;
+        k.windows = k.stage_entered[0];
+        uint64_t rect_evals = 0;
+        for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) {
+            k.stump_evals += k.stage_entered[s2] * pl2->prog.n_nodes[s2];
+            rect_evals += k.stage_entered[s2] * pl2->prog.n_rects[s2];
+        }
+        k.gather_bytes = 48ull * k.windows + 16ull * rect_evals;
+    }
+    return VJ_OK;
+}
+
+
 extern "C" {
 
 int vj_env_create(int device_index, vj_env** out) {
@@ -1427,6 +1606,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "tree_split_queues") == 0) {
         e->tree_split_queues = atoi(value) != 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "rois_on_device") == 0) {
+        e->rois_on_device = atoi(value) != 0;
         return VJ_OK;
     }
     if (strcmp(key, "thin_pass_spread") == 0) {
@@ -1753,6 +1936,21 @@ int vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int n
         }
         by_size[{r.w, r.h}].push_back(i);
     }
+    // frames of one size, a linear cascade, the exhaustive grid: every region in one pass on the frames' own integral images
+    if (n_rois > 0 && n_frames > 0 && !(p->flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW)) && (p->scale_mask[0] | p->scale_mask[1]) == 0 &&
+        p->scale_factor > 1.0f && e->rois_on_device) {
+        bool same = true;
+        for (int i = 0; i < n_frames && same; ++i)
+            same = frames[i].data && frames[i].width == frames[0].width && frames[i].height == frames[0].height &&
+                   image_channels(frames[i]) == image_channels(frames[0]) && frames[i].stride >= frames[i].width * image_channels(frames[i]);
+        bool linear = true;
+        for (const auto& st : c->stages) linear = linear && st.next == -1;
+        int W = 0, H = 0, CH = 0;
+        if (same && linear && check_frames(frames, n_frames, &W, &H, &CH) == VJ_OK) {
+            HIP_TRY(hipSetDevice(e->device));
+            return detect_rois_on_device(e, c, frames, n_frames, rois, n_rois, p, W, H, out);
+        }
+    }
     std::vector<vj_rect> all;
     for (const auto& kv : by_size) {
         std::vector<vj_image> views;
@@ -1898,49 +2096,12 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
             if ((rc = e->d_roi_det.ensure((size_t)e->roi_det_cap * sizeof(RoiDet)))) return rc;
             uint32_t* roi_counts = (uint32_t*)L->d_counts.p + CountsLayout::roi_off_u32;   // zeroed with the block by enqueue_cascade
             RoiArgs ra;
-            memset(&ra, 0, sizeof(ra));
+            CascadeArgs ca;
+            fill_region_args(e, L, pl2, second, *p_second, W, H, nf, L->det_cap, &ra, &ca);
             ra.det_in = (const DetEntry*)L->d_det.p;
             ra.det_in_count = (const uint32_t*)L->d_counts.p + MAX_PASSES * CountsLayout::q_counts;
             ra.det_in_cap = L->det_cap;
             ra.scales_in = (const ScaleDev*)pl1->d_scales.p;
-            ra.frame_bytes = pl1->frame_elems * 4u;
-            ra.stride = stride;
-            ra.rois = (RoiDev*)e->d_rois.p;
-            ra.n_rois = roi_counts + 0;
-            ra.max_rois = L->det_cap;
-            ra.n_frames = (uint32_t)nf;
-            ra.frame_w = W;
-            ra.frame_h = H;
-            ra.win_w0 = second->win_w;
-            ra.win_h0 = second->win_h;
-            ra.units = (RoiUnit*)e->d_roi_units.p;
-            ra.n_units = roi_counts + 1;   // (+2: invalid regions)
-            ra.max_units = e->roi_unit_cap;
-            ra.ticket = roi_counts + 3;
-            ra.det = (RoiDet*)e->d_roi_det.p;
-            ra.det_count = roi_counts + 4;
-            ra.det_cap = e->roi_det_cap;
-            CascadeArgs ca;
-            memset(&ca, 0, sizeof(ca));
-            ca.sum = (const uint32_t*)e->d_sum.p;
-            ca.sqsum = (const uint64_t*)e->d_sqsum.p;
-            ca.table = (const uint32_t*)pl2->d_table.p;
-            ca.scales = (const ScaleDev*)pl2->d_scales.p;
-            ca.stages = (const StageDev*)pl2->d_stages.p;
-            ca.n_frames = (uint32_t)nf;
-            ca.n_scales = (uint32_t)pl2->scales.size();
-            ca.frame_elems = pl2->frame_elems;
-            ca.sum_bytes = (uint32_t)((uint64_t)pl2->frame_elems * 4u * (uint64_t)nf);
-            ca.stride = stride;
-            ca.stage_begin = 0;
-            ca.stage_end = (uint32_t)pl2->stages.size();
-            ca.identity_order = 1u;
-            ca.tree2 = 0u;
-            ca.signed_mean = (p_second->flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
-            ca.gather_pairs = 2u;   // regions are small: thin waves, latency-bound
-            ca.sp_tail_max = (uint32_t)std::max(0, std::min(e->sp_tail_max, 48));
-            ca.max_stage_nodes = pl2->max_stage_nodes;
-            ca.stage_entered = (unsigned long long*)(roi_counts + 8);
             HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], e->stream));
             if (grouped) {
                 ga.n_rois = ra.n_rois;

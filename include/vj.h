@@ -179,7 +179,7 @@ int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
  * "tile_sp_begin", "tile_sp_max", "tile_ws_min", "tile_ws_max" = finish
  * thresholds, "tile_deinterleave", "tile_min_lanes", "max_subbatch", "det_cap", "gather_pairs" (stumps per step of the
  * global-gather sweeps: 0 one, 1 two for thin waves, 2 two always, -1 by batch size), "sp_tail_max" (a wave of the gather
- * sweeps with at most this many windows left finishes stump-parallel; 0 never), "seg_cut2", "plan_cache_max", "thin_pass_spread" (0/1), "tree_split_queues" (0/1), "group_max"
+ * sweeps with at most this many windows left finishes stump-parallel; 0 never), "seg_cut2", "plan_cache_max", "thin_pass_spread" (0/1), "rois_on_device" (0/1), "tree_split_queues" (0/1), "group_max"
  * (vj_detect_chain: raw candidates of one frame grouped on the device, <= 2048; a frame with more takes the host path).
  * Unknown keys return VJ_ERR_ARG.                                               */
 int  vj_env_configure(vj_env* e, const char* key, const char* value);
@@ -298,8 +298,12 @@ int  vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, in
 
 /* A second cascade on regions of interest (BASELINE config 5: haarcascade_eye inside every face;
  * the reference's caller would hand clodDetectObjects a sub-image header: pointer + widthStep).
- * ROIs are views into `frames`; ROIs of equal size share one batched pass.  In the result,
- * rect.frame is the ROI's index and x / y are relative to the ROI's origin.                  */
+ * ROIs are views into `frames`.  In the result, rect.frame is the ROI's index and x / y are relative
+ * to the ROI's origin.  Frames of one size with a linear cascade: the frames' integral images are
+ * computed once and ALL regions, of whatever sizes, run in one pass on them (a rectangle sum does not
+ * depend on where the integral image starts; vj_detect_chain's region pass with an uploaded list).
+ * Otherwise (frames of different sizes, stage trees, skip modes, a scale mask): one vj_detect call per
+ * region size on the sub-images.  Same result either way.                                        */
 typedef struct vj_roi { int32_t frame, x, y, w, h; } vj_roi;
 int  vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames,
                     const vj_roi* rois, int n_rois, const vj_params* p, vj_result* out);
