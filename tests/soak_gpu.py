@@ -31,9 +31,10 @@ NAMES = ["frontalface_alt", "frontalface_default", "frontalface_alt2", "eye", "f
 CASC = {n: (Cascade.load(n), load_vjc(os.path.join(DATA_DIR, f"haarcascade_{n}.vjc"))) for n in NAMES}
 TUNABLES = [("tile_split", ["0", "0.5", "1.3", "0,0.5,0.5"]), ("blocks_per_cu", ["1", "3", "8"]), ("gather_pairs", ["-1", "0", "2"]),
             ("sp_tail_max", ["0", "16", "48"]), ("thin_pass_spread", ["0", "1"]), ("tree_split_queues", ["0", "1"]), ("concurrent", ["0", "1"]),
-            ("tile_classes_kb", ["-2,-1,0", "0,0,0", "24,40,60"]), ("grid_block_w", ["0", "32"]), ("max_subbatch", ["0", "2"])]
+            ("tile_classes_kb", ["-2,-1,0", "0,0,0", "24,40,60"]), ("grid_block_w", ["0", "32"]), ("max_subbatch", ["0", "2"]),
+            ("group_max", ["2048", "30"]), ("rois_on_device", ["1", "0"])]
 DEFAULTS = {"tile_split": "0,0.5,0.5", "blocks_per_cu": "8", "gather_pairs": "-1", "sp_tail_max": "48", "thin_pass_spread": "1", "tree_split_queues": "1",
-            "concurrent": "1", "tile_classes_kb": "-2,-1,0", "grid_block_w": "32", "max_subbatch": "0"}
+            "concurrent": "1", "tile_classes_kb": "-2,-1,0", "grid_block_w": "32", "max_subbatch": "0", "group_max": "2048", "rois_on_device": "1"}
 
 
 def rows(r):
@@ -46,7 +47,7 @@ by_mode = {}
 seed = seed0
 while time.time() < t_end:
     rng = np.random.default_rng(770000 + seed)
-    mode = ["grid", "grid", "grid", "skip_list", "skip_row", "opencv", "chain", "chain_grouped"][int(rng.integers(0, 8))]
+    mode = ["grid", "grid", "grid", "skip_list", "skip_row", "opencv", "chain", "chain_grouped", "rois"][int(rng.integers(0, 9))]
     name = NAMES[int(rng.integers(0, len(NAMES)))]
     c, a = CASC[name]
     linear = bool(np.all(a.stage_next == -1))
@@ -92,6 +93,24 @@ while time.time() < t_end:
                 ok &= sorted(rows(r.rects[r.rects["frame"] == f])) == sorted(rows(ro))
             ok &= r.stage_entered == [v * nb for v in st["stage_entered"]] and r.windows == st["windows"] * nb
             desc += (mn, sf)
+        elif mode == "rois":                      # host-supplied regions of random sizes in a small batch
+            if not linear:
+                name = "eye"
+                c, a = CASC[name]
+            imgs = [img, make_frame(kind, 9100 + seed, h, w)][:max(1, min(nb, 2))]
+            rois = []
+            for _ in range(int(rng.integers(1, 9))):
+                rw_, rh_ = int(rng.integers(c.info.win_w + 11, max(c.info.win_w + 12, min(w, 260)))), int(rng.integers(c.info.win_h + 11, max(c.info.win_h + 12, min(h, 260))))
+                rw_, rh_ = min(rw_, w), min(rh_, h)
+                rois.append((int(rng.integers(0, len(imgs))), int(rng.integers(0, w - rw_ + 1)), int(rng.integers(0, h - rh_ + 1)), rw_, rh_))
+            r = env.detect_rois(c, imgs, rois, default_params(flags=VJ_FLAG_COUNTERS))
+            entered = np.zeros(len(r.stage_entered), np.int64)
+            for i, (f, x, y, ww, hh) in enumerate(rois):
+                ro, st = o.detect(a, np.ascontiguousarray(imgs[f][y:y + hh, x:x + ww]))
+                ok &= rows(r.rects[r.rects["frame"] == i]) == rows(ro)
+                entered += np.array(st["stage_entered"], np.int64)
+            ok &= r.stage_entered == entered.tolist()
+            desc += (rois,)
         else:
             if not linear or name == "eye":
                 name = "frontalface_alt2"
