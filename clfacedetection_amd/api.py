@@ -452,7 +452,8 @@ class Environment:
         return imgs, n, keep
 
     def detect_rois(self, cascade: Cascade, frames, rois, params: Params | None = None, color: bool = False) -> DetectResult:
-        """vj_detect_rois: `rois` = rows of (frame, x, y, w, h); ROIs of equal size share one batched pass.  In the
+        """vj_detect_rois: `rois` = rows of (frame, x, y, w, h), regions of any sizes (frames of one size and a linear
+        cascade: one pass for all of them on the frames' integral images; else one batched pass per region size).  In the
         result rects['frame'] is the ROI's row and x / y are relative to the ROI's origin."""
         p = params or default_params()
         imgs, n, keep = self._images(frames, color)
