@@ -22,6 +22,7 @@
 
 namespace vj {
 
+constexpr uint32_t CV_TREE_SEG_GROUPS = 16;   // stage trees: a row is resolved in segments of 16 x 64 grid positions
 struct CvQEntry {
     uint32_t off;   // byte offset of the window origin in the batch sum image
     uint32_t xy;    // x | y << 16
@@ -167,6 +168,7 @@ __device__ __forceinline__ bool cv_visited(unsigned long long F, uint32_t lane, 
 template <bool TREES, bool COUNT, bool STAGE_TREE>
 __global__ __launch_bounds__(CV_WAVES_PER_BLOCK * 64) void cv_profile_pass(CvArgs a) {
     __shared__ CvQEntry lds_q[CV_WAVES_PER_BLOCK * CV_QCAP];
+    __shared__ unsigned long long lds_words[CV_WAVES_PER_BLOCK][2][STAGE_TREE ? CV_TREE_SEG_GROUPS : 1];   // stage trees: verdict bits of a row segment
     const uint32_t lane = lane_id();
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     CvQEntry* q = lds_q + wib * CV_QCAP;
@@ -207,6 +209,105 @@ __global__ __launch_bounds__(CV_WAVES_PER_BLOCK * 64) void cv_profile_pass(CvArg
         const double thr0 = (double)stages[0].threshold;
         uint32_t carry = 0;   // parity of the run of rejects that ends at the last position seen
         uint32_t n_q = 0;
+        if (STAGE_TREE && !COUNT) {
+            // Stage tree, every grid position (the skip rule needs the whole tree's verdict everywhere), but not every
+            // position in lockstep to the end: the linear prefix runs on the dense groups; who is still inside the tree
+            // afterwards (a few percent) waits in the wave's queue with its target stage, and a FULL chunk of those
+            // sweeps the rest of the tree at a time — 64 lanes of survivors pay for the chains instead of every group
+            // of 64 positions paying for its deepest lane.  The verdict bits of a row segment (reject / accept words)
+            // sit in LDS until every position of the segment has one; then the walk is resolved group by group.
+            unsigned long long* Fw = lds_words[wib][0];
+            unsigned long long* Aw = lds_words[wib][1];
+            uint32_t prefix = 0;   // leading stages of the sweep order that reject outright and pass to the next one
+            while (prefix + 1u < a.n_order && stages[stages[prefix].order].on_fail == -2 &&
+                   stages[stages[prefix].order].on_pass == (int32_t)stages[prefix + 1u].order)
+                ++prefix;
+            auto drain = [&](uint32_t seg0) {
+                for (uint32_t base = 0; base < n_q; base += 64u) {
+                    const bool act = base + lane < n_q;
+                    const CvQEntry e = q[act ? base + lane : 0u];
+                    int32_t ptr = act ? (int32_t)(e.xy >> 16) : -3;
+                    for (uint32_t oi = prefix; oi < a.n_order; ++oi) {
+                        const uint32_t s = stages[oi].order;
+                        const bool here = ptr == (int32_t)s;
+                        if (__ballot(here) == 0ull) continue;
+                        if (here) {
+                            const bool pass = cv_stage_sum<TREES, false>(img, timg, table + stages[s].first_node, stages[s].n_nodes, e.off, e.vnf) >=
+                                              (double)stages[s].threshold;
+                            ptr = pass ? stages[s].on_pass : stages[s].on_fail;
+                        }
+                    }
+                    if (act) {
+                        const uint32_t rel = (e.xy & 0xffffu) - seg0;
+                        if (ptr == -2) atomicOr(Fw + (rel >> 6), 1ull << (rel & 63u));
+                        else if (ptr == -1) atomicOr(Aw + (rel >> 6), 1ull << (rel & 63u));
+                    }
+                }
+                n_q = 0;
+                __builtin_amdgcn_wave_barrier();
+            };
+            for (uint32_t seg0 = 0; seg0 < end_x; seg0 += CV_TREE_SEG_GROUPS * 64u) {
+                const uint32_t seg_end = min(end_x, seg0 + CV_TREE_SEG_GROUPS * 64u);
+                for (uint32_t ix0 = seg0; ix0 < seg_end; ix0 += 64u) {
+                    const uint32_t ix = ix0 + lane;
+                    const bool valid = ix < end_x;
+                    const uint32_t x = (uint32_t)cv_round((double)(valid ? ix : 0u) * ystep);
+                    const bool border = row_border || x + win_w >= a.stride;
+                    const uint32_t po = y * a.stride + x;
+                    const uint32_t off = frame_bytes + po * 4u;
+                    double vnf = 1.0;
+                    const bool eval = valid && !border;
+                    if (eval) {
+                        const int32_t isum = (int32_t)(ld_u32(img, off, q0 * 4u) - ld_u32(img, off, q1 * 4u) - ld_u32(img, off, q2 * 4u) +
+                                                       ld_u32(img, off, q3 * 4u));
+                        const uint64_t qq = ld_u64(sq_f, po * 8u, q0 * 8u) - ld_u64(sq_f, po * 8u, q1 * 8u) - ld_u64(sq_f, po * 8u, q2 * 8u) +
+                                            ld_u64(sq_f, po * 8u, q3 * 8u);
+                        const double mean = (double)isum * inv_area;
+                        vnf = (double)qq;
+                        vnf = vnf * inv_area - mean * mean;
+                        vnf = vnf >= 0.0 ? sqrt(vnf) : 1.0;
+                    }
+                    int32_t ptr = eval ? (int32_t)stages[0].order : -3;   // -1 accepted, -2 rejected, -3 not evaluated
+                    for (uint32_t oi = 0; oi < prefix; ++oi) {
+                        const uint32_t s = stages[oi].order;
+                        const bool here = ptr == (int32_t)s;
+                        if (__ballot(here) == 0ull) break;   // (nobody left in the prefix)
+                        if (here) {
+                            const bool pass = cv_stage_sum<TREES, false>(img, timg, table + stages[s].first_node, stages[s].n_nodes, off, vnf) >=
+                                              (double)stages[s].threshold;
+                            ptr = pass ? stages[s].on_pass : stages[s].on_fail;
+                        }
+                    }
+                    const unsigned long long fm = __ballot(ptr == -2), am = __ballot(ptr == -1), wm = __ballot(ptr >= 0);
+                    if (lane == 0) {
+                        Fw[(ix0 - seg0) >> 6] = fm;
+                        Aw[(ix0 - seg0) >> 6] = am;
+                    }
+                    if (ptr >= 0) q[n_q + mbcnt(wm)] = CvQEntry{off, ix | ((uint32_t)ptr << 16), vnf};
+                    n_q += (uint32_t)__popcll(wm);
+                    __builtin_amdgcn_wave_barrier();
+                    if (n_q > (uint32_t)CV_QCAP - 64u) drain(seg0);
+                }
+                drain(seg0);
+                // every position of the segment has its verdict: the sequential walk, group by group
+                for (uint32_t ix0 = seg0; ix0 < seg_end; ix0 += 64u) {
+                    const uint32_t ix = ix0 + lane;
+                    const unsigned long long F = Fw[(ix0 - seg0) >> 6], A = Aw[(ix0 - seg0) >> 6];
+                    const bool visited = cv_visited(F, lane, min(64u, end_x - ix0), carry);
+                    const bool hit = visited && ((A >> lane) & 1ull) != 0ull;
+                    const unsigned long long hm = __ballot(hit);
+                    if (hm != 0ull) {
+                        uint32_t g = 0;
+                        if (lane == 0) g = atomicAdd(a.det_count, (uint32_t)__popcll(hm));
+                        g = __builtin_amdgcn_readfirstlane(g);
+                        const uint32_t pos = g + mbcnt(hm);
+                        if (hit && pos < a.det_cap) a.det[pos] = CvDet{(uint32_t)cv_round((double)ix * ystep), y, slot, frame};
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            continue;
+        }
         for (uint32_t ix0 = 0; ix0 < end_x; ix0 += 64u) {
             const uint32_t ix = ix0 + lane;
             const bool valid = ix < end_x;
