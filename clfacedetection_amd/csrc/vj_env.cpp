@@ -925,6 +925,7 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
             qa.q_in_count = qc[ps];
             qa.q_ticket = qc[0] + ps * Q_PARTS;   // queue 0 does not exist: its counters serve as tickets
             qa.thin_pass_spread = e->thin_pass_spread ? 1u : 0u;
+            qa.wide_tail = (e->wide_tail < 0 ? nf <= 4 : e->wide_tail != 0) ? 1u : 0u;
             qa.q_out = last ? nullptr : (QEntry*)dq[ps + 1].p;
             qa.q_out_count = last ? nullptr : qc[ps + 1];
             if (!pl->seg_fail.empty() && pl->seg_fail[ps] != 0) {   // stage tree: this segment's rejects continue
@@ -1613,6 +1614,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "rois_on_device") == 0) {
         e->rois_on_device = atoi(value) != 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "wide_tail") == 0) {
+        e->wide_tail = std::max(-1, std::min(atoi(value), 1));   // -1: by batch size
         return VJ_OK;
     }
     if (strcmp(key, "thin_pass_spread") == 0) {

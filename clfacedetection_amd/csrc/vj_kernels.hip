@@ -584,8 +584,12 @@ struct FailSink {
 constexpr uint32_t SP_TAIL_MAX = 48;          // windows at most: 48 entries (384 B) + 48 x 9 verdict words (3456 B) fit the wave's 4 KiB queue
 constexpr uint32_t SP_TAIL_MAX_BLOCKS = 9;    // blocks of 64 stumps per stage at most (stages of <= 576 nodes)
 constexpr uint32_t SP_TAIL_MAX_NODES = SP_TAIL_MAX_BLOCKS * 64u;
+#ifndef VJ_TAIL_NW
+#define VJ_TAIL_NW 2
+#endif
+constexpr int TAIL_NW = VJ_TAIL_NW;            // windows per step of the tail in the queue passes of small batches (CascadeArgs::wide_tail)
 
-template <bool COUNT>
+template <bool COUNT, int NW = 1>
 __device__ __forceinline__ uint32_t sweep_tail_stump_parallel(const CascadeArgs& a, rsrc_t img_r, kptr<NodeRecDev> table, QEntry* q, uint32_t n,
                                                               uint32_t lane, uint32_t begin, uint32_t end, FailSink fail) {
     kptr<StageDev> stages = as_k(a.stages);
@@ -608,7 +612,38 @@ __device__ __forceinline__ uint32_t sweep_tail_stump_parallel(const CascadeArgs&
             r[0] = r0.x; r[1] = r0.y; r[2] = r0.z; r[3] = r0.w; r[4] = r1.x; r[5] = r1.y; r[6] = r1.z; r[7] = r1.w;
             r[8] = r2.x; r[9] = r2.y; r[10] = r2.z; r[11] = r2.w; r[12] = r3.x; r[13] = r3.y; r[14] = r3.z; r[15] = r3.w;
             const float thr_node = __uint_as_float(r[11]);
-            for (uint32_t w = 0; w < n; ++w) {
+            uint32_t w = 0;
+            if constexpr (NW > 1) {
+                // NW windows per step, all of their gathers in flight before the first verdict (instantiated for the queue
+                // passes of small batches: a cluster of detections sits in ONE wave, which then pays windows x blocks
+                // memory round trips per stage)
+                const uint32_t lt0 = r[0], lt1 = r[1], lt2 = r[2], dh0 = r[3], dh1 = r[4], dh2 = r[5];
+                const uint32_t dw0 = (uint32_t)(int32_t)(int16_t)(r[6] & 0xffffu), dw1 = (uint32_t)((int32_t)r[6] >> 16),
+                               dw2 = (uint32_t)(int32_t)(int16_t)(r[7] & 0xffffu);
+                const float w0 = __uint_as_float(r[8]), w1 = __uint_as_float(r[9]), w2 = __uint_as_float(r[10]);
+                for (; w + (uint32_t)NW <= n; w += (uint32_t)NW) {
+                    uint32_t c[NW][12];
+                    float var[NW];
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) {   // (an absent third rectangle reads four in-range dwords)
+                        const QEntry e = q[w + (uint32_t)k];
+                        var[k] = e.var;
+                        c[k][0] = img.ld(e.off, lt0); c[k][1] = img.ld(e.off, lt0 + dw0); c[k][2] = img.ld(e.off, lt0 + dh0); c[k][3] = img.ld(e.off, lt0 + dh0 + dw0);
+                        c[k][4] = img.ld(e.off, lt1); c[k][5] = img.ld(e.off, lt1 + dw1); c[k][6] = img.ld(e.off, lt1 + dh1); c[k][7] = img.ld(e.off, lt1 + dh1 + dw1);
+                        c[k][8] = img.ld(e.off, lt2); c[k][9] = img.ld(e.off, lt2 + dw2); c[k][10] = img.ld(e.off, lt2 + dh2); c[k][11] = img.ld(e.off, lt2 + dh2 + dw2);
+                    }
+#pragma unroll
+                    for (int k = 0; k < NW; ++k) {   // node_rect_sum's arithmetic (clod.cl:60-76)
+                        float rect_sum = (float)(c[k][0] - c[k][1] - c[k][2] + c[k][3]) * w0;
+                        rect_sum += (float)(c[k][4] - c[k][5] - c[k][6] + c[k][7]) * w1;
+                        const float with2 = rect_sum + (float)(c[k][8] - c[k][9] - c[k][10] + c[k][11]) * w2;
+                        rect_sum = w2 != 0.0f ? with2 : rect_sum;
+                        const unsigned long long m = __ballot(active && rect_sum >= thr_node * var[k]);
+                        if (lane == 0) masks[(w + (uint32_t)k) * SP_TAIL_MAX_BLOCKS + b] = m;
+                    }
+                }
+            }
+            for (; w < n; ++w) {
                 const QEntry e = q[w];   // broadcast
                 const float sum = node_rect_sum(img, r, e.off);
                 const unsigned long long m = __ballot(active && sum >= thr_node * e.var);
@@ -658,7 +693,7 @@ __device__ __forceinline__ uint32_t sweep_tail_stump_parallel(const CascadeArgs&
     return n;
 }
 
-template <bool TREES, bool COUNT, bool MULTI = false, typename Img>
+template <bool TREES, bool COUNT, bool MULTI = false, int NW = 1, typename Img>
 __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img& img, kptr<NodeRecDev> table,
                                                  QEntry* q, uint32_t n, uint32_t lane, uint32_t begin, uint32_t end,
                                                  FailSink fail = FailSink()) {
@@ -671,7 +706,7 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
         if constexpr (!TREES && !MULTI && std::is_same<Img, GlobalImg>::value) {
             // a handful of windows left: the rest of the sweep stump-parallel (uniform decision)
             if (a.sp_tail_max != 0u && n <= a.sp_tail_max && a.max_stage_nodes <= SP_TAIL_MAX_NODES)
-                return sweep_tail_stump_parallel<COUNT>(a, img.r, table, q, n, lane, pos, end, fail);
+                return sweep_tail_stump_parallel<COUNT, NW>(a, img.r, table, q, n, lane, pos, end, fail);
         }
         const float threshold = stages[s].threshold;
         if (COUNT && lane == 0) atomicAdd(a.stage_entered + s, (unsigned long long)n);
@@ -778,7 +813,7 @@ __device__ __forceinline__ uint32_t frame_part(const CascadeArgs& a, uint32_t fr
 
 // Global-gather pass body: sweep the stages, then hand the survivors to the next pass's
 // global queue (or to the detection list).
-template <bool TREES, bool LAST, bool COUNT>
+template <bool TREES, bool LAST, bool COUNT, int NW = 1>
 __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t img_r, QEntry* q, uint32_t n,
                                                   uint32_t scale_slot, uint32_t table_first, uint32_t q_base,
                                                   uint32_t lane, uint32_t begin, uint32_t part) {
@@ -789,7 +824,7 @@ __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t i
         fail.base = a.q_fail + ((size_t)q_base + (size_t)part * as_k(a.scales)[scale_slot].q_cap);
         fail.count = a.q_fail_count + scale_slot * Q_PARTS + part;
     }
-    n = sweep_stages<TREES, COUNT>(a, img, table, q, n, lane, begin, a.stage_end, fail);
+    n = sweep_stages<TREES, COUNT, false, NW>(a, img, table, q, n, lane, begin, a.stage_end, fail);
     if (n == 0u) return;
     if (LAST) {
         uint32_t g = 0;
@@ -863,7 +898,7 @@ __device__ __forceinline__ void run_stages_general(const CascadeArgs& a, rsrc_t 
     }
 }
 
-template <bool FROM_GRID, bool TREES, bool LAST, bool COUNT, bool GENERAL>
+template <bool FROM_GRID, bool TREES, bool LAST, bool COUNT, bool GENERAL, int NW = 1>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs a) {
     __shared__ QEntry lds_q[WAVES_PER_BLOCK * UNIT_WINDOWS];
     __shared__ int32_t lds_tgt[GENERAL ? WAVES_PER_BLOCK * UNIT_WINDOWS : 1];
@@ -1024,7 +1059,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
             if (GENERAL)   // the rest of a stage tree, for the survivors of its linear prefix
                 run_stages_general<TREES, COUNT>(a, img, q, lds_tgt + wib * UNIT_WINDOWS, n, slot, scales[slot].table_first, lane);
             else
-                run_stages_linear<TREES, LAST, COUNT>(a, img, q, n, slot, scales[slot].table_first, q_base, lane, a.stage_begin, part);
+                run_stages_linear<TREES, LAST, COUNT, NW>(a, img, q, n, slot, scales[slot].table_first, q_base, lane, a.stage_begin, part);
             __builtin_amdgcn_wave_barrier();
             if (VJ_STAMPS && lane == 0) {   // diagnostic build: time per chunk of a queue pass (sum, max, chunks)
                 const unsigned long long dt = __builtin_amdgcn_s_memtime() - t_chunk;
@@ -2081,6 +2116,18 @@ int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, bool 
 template <bool FROM_GRID, bool TREES>
 static void launch_variant(const CascadeArgs& a, bool last, bool count, int n_blocks, hipStream_t stream) {
     dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
+    if constexpr (!FROM_GRID && !TREES) {
+        if (a.wide_tail != 0u) {   // queue passes of a small batch: TAIL_NW windows per step of the stump-parallel tail
+            if (last) {
+                if (count) hipLaunchKernelGGL((cascade_pass<false, false, true, true, false, TAIL_NW>), g, b, 0, stream, a);
+                else       hipLaunchKernelGGL((cascade_pass<false, false, true, false, false, TAIL_NW>), g, b, 0, stream, a);
+            } else {
+                if (count) hipLaunchKernelGGL((cascade_pass<false, false, false, true, false, TAIL_NW>), g, b, 0, stream, a);
+                else       hipLaunchKernelGGL((cascade_pass<false, false, false, false, false, TAIL_NW>), g, b, 0, stream, a);
+            }
+            return;
+        }
+    }
     if (last) {
         if (count) hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, true, false>), g, b, 0, stream, a);
         else       hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, false, false>), g, b, 0, stream, a);
