@@ -707,6 +707,58 @@ int stage_frames(vj_env* e, const vj_image* frames, int n, int W, int H, const u
         return VJ_OK;
     }
     const size_t gstride = (row_bytes + 3) & ~(size_t)3;
+    bool all_host = true;
+    for (int i = 0; i < n; ++i) all_host = all_host && !frames[i].on_device;
+    if (all_host && contiguous && (size_t)frames[0].stride == gstride && n > 1) {
+        // a batch that is one block on the host with the device's pitch (a numpy array of n frames): ONE copy instead of n
+        // (2048 frames of 100 x 100: 24 ms of per-frame copy calls)
+        const size_t bytes = gstride * (size_t)H * (size_t)n;
+        const void* src = frames[0].data;
+        if (copy_stream) {   // streams: a true DMA — page-locked memory as it is, pageable memory through the staging buffer
+            hipPointerAttribute_t at;
+            const bool pinned = hipPointerGetAttributes(&at, src) == hipSuccess && at.type == hipMemoryTypeHost;
+            if (!pinned) {
+                (void)hipGetLastError();
+                if (lane->h_stage_bytes < bytes) {
+                    if (lane->h_stage) (void)hipHostFree(lane->h_stage);
+                    lane->h_stage = nullptr;
+                    lane->h_stage_bytes = 0;
+                    HIP_TRY(hipHostMalloc(&lane->h_stage, bytes, hipHostMallocDefault));
+                    lane->h_stage_bytes = bytes;
+                }
+                memcpy(lane->h_stage, src, bytes);
+                src = lane->h_stage;
+            }
+        }
+        HIP_TRY(hipMemcpyAsync(lane->d_gray.p, src, bytes, hipMemcpyHostToDevice, cs));
+        *d_ptr = (const uint8_t*)lane->d_gray.p;
+        *stride = (int)gstride;
+        *frame_bytes = gstride * (size_t)H;
+        return VJ_OK;
+    }
+    if (all_host && n >= 4 && gstride * (size_t)H <= ((size_t)256 << 10)) {
+        // many small frames in separate host buffers: gather them in the page-locked staging buffer (at the device's pitch)
+        // and send one block — a copy call per frame costs more than copying a few KB twice
+        const size_t fb = gstride * (size_t)H, bytes = fb * (size_t)n;
+        if (lane->h_stage_bytes < bytes) {
+            if (lane->h_stage) (void)hipHostFree(lane->h_stage);
+            lane->h_stage = nullptr;
+            lane->h_stage_bytes = 0;
+            HIP_TRY(hipHostMalloc(&lane->h_stage, bytes, hipHostMallocDefault));
+            lane->h_stage_bytes = bytes;
+        }
+        for (int i = 0; i < n; ++i) {
+            uint8_t* st = (uint8_t*)lane->h_stage + (size_t)i * fb;
+            if ((size_t)frames[i].stride == gstride) memcpy(st, frames[i].data, fb);
+            else
+                for (int y = 0; y < H; ++y) memcpy(st + (size_t)y * gstride, frames[i].data + (size_t)y * (size_t)frames[i].stride, row_bytes);
+        }
+        HIP_TRY(hipMemcpyAsync(lane->d_gray.p, lane->h_stage, bytes, hipMemcpyHostToDevice, cs));
+        *d_ptr = (const uint8_t*)lane->d_gray.p;
+        *stride = (int)gstride;
+        *frame_bytes = fb;
+        return VJ_OK;
+    }
     for (int i = 0; i < n; ++i) {
         uint8_t* dst = (uint8_t*)lane->d_gray.p + (size_t)i * gstride * (size_t)H;
         const uint8_t* src = frames[i].data;

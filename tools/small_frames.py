@@ -3,6 +3,8 @@ sys.path.insert(0, os.getcwd())
 import numpy as np
 from clfacedetection_amd import Cascade, Environment, default_params, synth
 env = Environment(0)
+for kv in sys.argv[1:]:
+    env.configure(*kv.split("=", 1))
 for name, h, w, mn in (("frontalface_default", 480, 640, 3), ("frontalface_alt", 480, 640, 0), ("frontalface_alt", 240, 320, 0), ("eye", 100, 100, 0)):
     c = Cascade.load(name); img = synth.frame("faces" if h >= 240 else "noise", 2, h, w)
     p = default_params(min_neighbors=mn)
