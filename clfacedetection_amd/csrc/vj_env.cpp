@@ -533,10 +533,21 @@ static int layout_queues(Plan* pl, int frames, uint64_t* total_entries) {
     return VJ_OK;
 }
 
+// One or two SMALL frames per call are bound by the latency of the gather chain (most of their scales are "large" for the
+// batch thresholds: a 320 x 240 frame keeps two scales on tiles), and a tile with few windows is still far cheaper than
+// the thin waves of the queue pass: 320 x 240 0.78 -> 0.46 ms with tiles of >= 64 windows, 640 x 480 0.80 -> 0.76 with
+// >= 256 (tools/small_frames.py).  Batches keep the thresholds that make their tiles efficient (tools/many_small.py).
+static int small_frame_class(const vj_env* e, int W, int H, int n_frames) {
+    if (e->tile_thresholds_set || n_frames > 2) return 0;
+    const long long px = (long long)W * H;
+    return px <= 115200 ? 2 : px <= 460800 ? 1 : 0;
+}
+
 static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, Plan** out, int n_frames = 1 << 20) {
     const float split = e->split_for(n_frames);
+    const int small = small_frame_class(e, W, H, n_frames);
     vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
-                        p.scale_mask[1], p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW), f2u(split));
+                        p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW)) | ((uint32_t)small << 8), f2u(split));
     auto it = e->plans.find(key);
     if (it != e->plans.end()) {
         it->second->last_used = ++e->plan_tick;
@@ -556,7 +567,15 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
         }
     }
     auto pl = std::make_unique<Plan>();
+    const int keep[3] = {e->tile_min_windows, e->tile_accept_windows, e->tile_max_dwords_per_window};
+    if (small) {
+        e->tile_min_windows = e->tile_accept_windows = small == 2 ? 64 : 256;
+        e->tile_max_dwords_per_window = small == 2 ? 8000 : 2000;
+    }
     int rc = build_plan(e, *c, W, H, p, pl.get(), split);
+    e->tile_min_windows = keep[0];
+    e->tile_accept_windows = keep[1];
+    e->tile_max_dwords_per_window = keep[2];
     if (rc) {
         pl->release_device();
         return rc;
@@ -1722,6 +1741,7 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
          : strcmp(key, "tile_end") == 0           ? e->tile_end
          : strcmp(key, "tile_accept_windows") == 0 ? e->tile_accept_windows
                                                   : e->tile_min_lanes) = v;
+        if (strcmp(key, "tile_end") != 0 && strcmp(key, "tile_min_lanes") != 0) e->tile_thresholds_set = true;   // the caller's choice holds for every frame size
         HIP_TRY(hipStreamSynchronize(e->stream));
         drop_plans(e);
         return VJ_OK;

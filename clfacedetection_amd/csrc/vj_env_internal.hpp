@@ -199,6 +199,7 @@ struct vj_env {
                                                      // workgroups share a CU's 160 KiB; all 0 disables the tile path
     int tile_min_windows = 768;   // a class is acceptable for a scale when a tile holds at least this many windows
     int tile_max_dwords_per_window = 600;  // staging a tile must stay far cheaper than gathering its windows from L2
+    bool tile_thresholds_set = false;   // the three thresholds were configured: no per-frame-size defaults (get_plan)
     int tile_accept_windows = 768;  // scales whose best tile holds fewer windows stay on the global-gather path
     int tile_end = 64;            // tile launches never enter a pass that begins at or beyond this stage
     int tile_min_lanes = 0;       // a tile leaves at a pass boundary when fewer windows than this survive in it
