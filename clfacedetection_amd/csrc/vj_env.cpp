@@ -67,7 +67,15 @@ static std::vector<uint32_t> default_pass_bounds(const vj_cascade& c, const Stag
     return b;
 }
 
-static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_params& p, Plan* pl, float tile_split) {
+// Which scales go to LDS tiles: a class is acceptable for a scale when a tile holds at least min_windows windows, a scale
+// whose best tile holds fewer than accept_windows stays on the global-gather path, and staging a tile may cost at most
+// max_dwords_per_window.
+struct TileThresholds {
+    int min_windows, accept_windows, max_dwords_per_window;
+};
+
+static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_params& p, Plan* pl, float tile_split,
+                      const TileThresholds& thresholds) {
     pl->tile_split = tile_split;
     if ((int)c.stages.size() > VJ_MAX_STAGES) {
         set_error("cascade has %zu stages; at most %d are supported", c.stages.size(), VJ_MAX_STAGES);
@@ -186,7 +194,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
             // candidate tile shapes; per class the shape with the most windows that fits wins
             static const uint32_t kTw[] = {64, 48, 32, 24, 16, 12, 8}, kTh[] = {32, 24, 16, 12, 8, 6, 4};
             uint32_t best_cls = TILE_CLASSES, best_n = 0, b_tw = 0, b_th = 0, b_pitch = 0, b_rows = 0;
-            for (uint32_t cls = 0; cls < TILE_CLASSES && best_n < (uint32_t)e->tile_min_windows; ++cls) {
+            for (uint32_t cls = 0; cls < TILE_CLASSES && best_n < (uint32_t)thresholds.min_windows; ++cls) {
                 const int kb = e->tile_class_kb[cls];
                 const uint32_t lds_cu = (160u - (uint32_t)e->tile_lds_reserve_kb) * 1024u;
                 // (2 KiB of the CU's share stay free so that the nested class blocks below can be rounded up to whole
@@ -211,11 +219,11 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                         const uint32_t rows = (uint32_t)std::ceil((double)(th - 1) * (double)si.step) + 3u + reach_y;
                         if ((uint64_t)pitch * rows * 4u > budget) continue;
                         // staging a tile must stay far cheaper than gathering its windows from L2
-                        if ((uint64_t)pitch * rows > (uint64_t)e->tile_max_dwords_per_window * nwt) continue;
+                        if ((uint64_t)pitch * rows > (uint64_t)thresholds.max_dwords_per_window * nwt) continue;
                         best_cls = cls; best_n = nwt; b_tw = tw; b_th = th; b_pitch = pitch; b_rows = rows;
                     }
             }
-            if (best_n >= (uint32_t)e->tile_accept_windows) {
+            if (best_n >= (uint32_t)thresholds.accept_windows) {
                 sd.tile_rw = 1;
                 sd.tile_tw = b_tw;
                 sd.tile_th = b_th;
@@ -567,15 +575,10 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
         }
     }
     auto pl = std::make_unique<Plan>();
-    const int keep[3] = {e->tile_min_windows, e->tile_accept_windows, e->tile_max_dwords_per_window};
-    if (small) {
-        e->tile_min_windows = e->tile_accept_windows = small == 2 ? 64 : 256;
-        e->tile_max_dwords_per_window = small == 2 ? 8000 : 2000;
-    }
-    int rc = build_plan(e, *c, W, H, p, pl.get(), split);
-    e->tile_min_windows = keep[0];
-    e->tile_accept_windows = keep[1];
-    e->tile_max_dwords_per_window = keep[2];
+    TileThresholds th{e->tile_min_windows, e->tile_accept_windows, e->tile_max_dwords_per_window};
+    if (small == 2) th = TileThresholds{64, 64, 8000};
+    else if (small == 1) th = TileThresholds{256, 256, 2000};
+    int rc = build_plan(e, *c, W, H, p, pl.get(), split, th);
     if (rc) {
         pl->release_device();
         return rc;
@@ -2390,7 +2393,8 @@ int vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int 
         vj_stream* s;
         ~Guard() { if (s) vj_stream_destroy(s); }
     } guard{nullptr};
-    int rc = build_plan(e, *c, width, height, *p, s->plan.get(), e->split_for(max_batch));
+    int rc = build_plan(e, *c, width, height, *p, s->plan.get(), e->split_for(max_batch),
+                        TileThresholds{e->tile_min_windows, e->tile_accept_windows, e->tile_max_dwords_per_window});
     if (rc) {
         s->plan->release_device();
         return rc;
