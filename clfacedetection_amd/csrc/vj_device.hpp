@@ -150,6 +150,7 @@ struct CascadeArgs {
     const uint32_t* q_in_count; // entry counts of q_in, [scale][Q_PARTS]
     uint32_t* q_ticket;         // Q_PARTS chunk-ticket counters of this queue pass (zeroed before the launch)
     uint32_t wide_tail;         // queue passes: the stump-parallel tail keeps several windows' gathers in flight (small batches)
+    uint32_t min_chunk;         // queue passes: smallest chunk of windows a wave draws (1..64)
     uint32_t thin_pass_spread;  // queue passes with fewer chunks than waves: only the first workgroups draw tickets (even load per CU)
     QEntry*   q_out;            // survivor queue written by this pass (not the last)
     uint32_t* q_out_count;

@@ -999,6 +999,7 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
             qa.q_in_count = qc[ps];
             qa.q_ticket = qc[0] + ps * Q_PARTS;   // queue 0 does not exist: its counters serve as tickets
             qa.thin_pass_spread = e->thin_pass_spread ? 1u : 0u;
+            qa.min_chunk = (uint32_t)e->min_chunk;
             qa.wide_tail = (e->wide_tail < 0 ? nf <= 4 : e->wide_tail != 0) ? 1u : 0u;
             qa.q_out = last ? nullptr : (QEntry*)dq[ps + 1].p;
             qa.q_out_count = last ? nullptr : qc[ps + 1];
@@ -1692,6 +1693,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "wide_tail") == 0) {
         e->wide_tail = std::max(-1, std::min(atoi(value), 1));   // -1: by batch size
+        return VJ_OK;
+    }
+    if (strcmp(key, "min_chunk") == 0) {
+        e->min_chunk = std::max(1, std::min(atoi(value), 64));
         return VJ_OK;
     }
     if (strcmp(key, "thin_pass_spread") == 0) {

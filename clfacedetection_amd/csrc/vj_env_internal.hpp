@@ -218,6 +218,7 @@ struct vj_env {
     bool tree_split_queues = true; // stage trees: the grid pass's survivors go down the tree while the tiles still run
     bool rois_on_device = true;   // vj_detect_rois: one region pass on the frames' integral images (0: one vj_detect per region size)
     int wide_tail = -1;           // queue passes: several windows in flight in the stump-parallel tail (-1: batches of <= 4 frames)
+    int min_chunk = 32;           // queue passes: smallest chunk of windows a wave draws when there are fewer than 64 per wave
     bool thin_pass_spread = true; // queue passes with fewer chunks than waves: only the first workgroups draw tickets
     int sp_tail_max = 48;         // global-gather sweeps switch to the stump-parallel tail when a wave holds at most this many windows (0: never)
     int gather_pairs = -1;        // global-gather sweeps evaluate two stumps per step, all their gathers in flight together: 0 never, 1 for

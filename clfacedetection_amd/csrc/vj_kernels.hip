@@ -1005,7 +1005,13 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
             return (uint32_t)__builtin_amdgcn_readfirstlane(v);
         };
         total = wave_total(total);
-        const uint32_t chunk = min((uint32_t)UNIT_WINDOWS, max(64u, ((total / a.total_waves + 63u) / 64u) * 64u));
+        // With fewer windows than 64 per wave the chunks shrink further (a.min_chunk, 32 by default): the thin waves of a late
+        // pass are bound by windows x blocks memory round trips each, and a cluster of detections — neighbours in the queue —
+        // then spreads over two waves instead of sitting in one (16 and 8 make the populous passes of a stage tree slower).
+        const uint32_t min_chunk = max(1u, min(a.min_chunk, 64u));
+        const uint32_t per_wave = total / a.total_waves;
+        const uint32_t chunk = per_wave >= 64u ? min((uint32_t)UNIT_WINDOWS, ((per_wave + 63u) / 64u) * 64u)
+                                               : max(min_chunk, ((per_wave + min_chunk - 1u) / min_chunk) * min_chunk);
         if (a.thin_pass_spread != 0u) {
             // Fewer chunks than waves (a late pass, a single frame): whichever waves draw the tickets first get the
             // chunks, and with 24 resident waves per CU some CUs end up with twice the average — the pass then waits for

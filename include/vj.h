@@ -179,7 +179,7 @@ int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
  * "tile_sp_begin", "tile_sp_max", "tile_ws_min", "tile_ws_max" = finish
  * thresholds, "tile_deinterleave", "tile_min_lanes", "max_subbatch", "det_cap", "gather_pairs" (stumps per step of the
  * global-gather sweeps: 0 one, 1 two for thin waves, 2 two always, -1 by batch size), "sp_tail_max" (a wave of the gather
- * sweeps with at most this many windows left finishes stump-parallel; 0 never), "seg_cut2", "plan_cache_max", "thin_pass_spread" (0/1), "wide_tail" (queue passes: two windows' gathers in flight in the stump-parallel tail; 0/1, -1 = batches of <= 4 frames), "rois_on_device" (0/1), "tree_split_queues" (0/1), "group_max"
+ * sweeps with at most this many windows left finishes stump-parallel; 0 never), "seg_cut2", "plan_cache_max", "thin_pass_spread" (0/1), "min_chunk" (queue passes: smallest chunk of windows a wave draws, 1..64), "wide_tail" (queue passes: two windows' gathers in flight in the stump-parallel tail; 0/1, -1 = batches of <= 4 frames), "rois_on_device" (0/1), "tree_split_queues" (0/1), "group_max"
  * (vj_detect_chain: raw candidates of one frame grouped on the device, <= 2048; a frame with more takes the host path).
  * Unknown keys return VJ_ERR_ARG.                                               */
 int  vj_env_configure(vj_env* e, const char* key, const char* value);
