@@ -32,6 +32,7 @@ VJ_FLAG_COUNTERS = 1 << 0
 VJ_FLAG_SIGNED_MEAN = 1 << 1
 VJ_FLAG_SKIP_LIST = 1 << 2     # the CLOD_PER_STAGE_ITERATIONS CPU variant's skip over the flattened window list (clod.cpp:729-732)
 VJ_FLAG_SKIP_ROW = 1 << 3      # the plain CPU variant: round() positions, skip inside a row (clod.cpp:1409-1432)
+VJ_FLAG_GRID_F64 = 1 << 4      # + one of the two above: the same loop of the block variant, whose step is a double (clod.cpp:862)
 
 # clod_flags of the reference (clod.h:17-19).  They select among the reference's CPU
 # evaluators; the HIP path has one evaluator, so they are accepted and ignored.
@@ -197,9 +198,13 @@ def default_params(**kw) -> Params:
     p = Params()
     load_library().vj_params_default(C.byref(p))
     for k, v in kw.items():
-        if k == "scales":          # iterable of scale indices -> scale_mask
+        if k == "scales":          # iterable of scale indices -> scale_mask; an empty one = no scale (VJ_SCALE_MASK_NONE)
             for i in v:
+                if not 0 <= i < 127:
+                    raise ValueError("scale indices in a mask must be below 127")
                 p.scale_mask[i >> 6] |= 1 << (i & 63)
+            if (p.scale_mask[0] | p.scale_mask[1]) == 0:
+                p.scale_mask[1] = 1 << 63
         else:
             setattr(p, k, v)
     return p
@@ -289,7 +294,7 @@ class Cascade:
         p = params or default_params()
         m = (C.c_uint64 * 2)()
         _check(load_library().vj_shard_scales(self._h, width, height, C.byref(p), world, rank, m), "vj_shard_scales")
-        return [k for k in range(128) if (m[k >> 6] >> (k & 63)) & 1]
+        return [k for k in range(127) if (m[k >> 6] >> (k & 63)) & 1]      # bit 127 = VJ_SCALE_MASK_NONE: an empty share
 
     def count_windows(self, width: int, height: int, params: Params | None = None) -> int:
         p = params or default_params()
@@ -504,7 +509,7 @@ class Environment:
                                 [dict(kind=LAUNCH_KINDS.get(int(l.kind), "?"), lds_class=int(l.lds_class),
                                       stage_begin=int(l.stage_begin), stage_end=int(l.stage_end), ms=float(l.ms),
                                       lds_bytes=int(l.lds_bytes),
-                                      scales=[k for k in range(128) if (l.scale_mask[k >> 6] >> (k & 63)) & 1],
+                                      scales=[k for k in range(127) if (l.scale_mask[k >> 6] >> (k & 63)) & 1],
                                       stage_entered=[int(v) for v in l.stage_entered[:cascade.info.n_stages]])
                                  for l in list(t.launch)[:int(t.n_launches)]])
         finally:
@@ -632,11 +637,10 @@ def clodDetectObjects(image, cascade: Cascade, env: Environment, min_window_size
     (clod.cpp:1176-1336).  `image` may also be a batch (see Environment.detect)."""
     if not use_opencl:
         # the reference's CPU evaluators (clod.cpp:1358-1499) return the skip-thinned window set; the device computes the
-        # same set for its two non-"block" loops.  The block variant (clod.cpp:821-1173) keeps `step` in double and is
-        # a third grid: not implemented.
-        if flags & CLOD_BLOCK_IMPLEMENTATION:
-            raise VjError(4, "clodDetectObjects", "CLOD_BLOCK_IMPLEMENTATION (f64 step, clod.cpp:862) is not implemented")
+        # same set.  The block variant (clod.cpp:821-1173) keeps `step` in double: two more grids (VJ_FLAG_GRID_F64).
         vj_flags |= VJ_FLAG_SKIP_LIST if flags & CLOD_PER_STAGE_ITERATIONS else VJ_FLAG_SKIP_ROW
+        if flags & CLOD_BLOCK_IMPLEMENTATION:
+            vj_flags |= VJ_FLAG_GRID_F64
     p = default_params(min_w=int(min_window_size[0]), min_h=int(min_window_size[1]),
                        max_w=int(max_window_size[0]), max_h=int(max_window_size[1]),
                        min_neighbors=int(min_neighbors), flags=int(vj_flags))

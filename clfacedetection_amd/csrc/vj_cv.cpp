@@ -263,6 +263,10 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
     }
     const int W = frames[0].width, H = frames[0].height;
     if (W <= 0 || H <= 0 || W >= 65535 || H >= 65535) return VJ_ERR_ARG;
+    if ((uint64_t)(W + 1) * (uint64_t)(H + 3) >= (1ull << 30)) {   // the limit of vj_detect (check_frames): 32-bit byte offsets
+        set_error("image too large");                              // into one frame's sum image
+        return VJ_ERR_LIMIT;
+    }
     const int CH = image_channels(frames[0]);
     for (int i = 0; i < n_frames; ++i)
         if (!frames[i].data || frames[i].width != W || frames[i].height != H || image_channels(frames[i]) != CH ||

@@ -195,7 +195,7 @@ struct CascadeArgs {
     uint32_t  sp_tail_max;              // global-gather sweeps: at most this many windows left in a wave -> stump-parallel tail (0: off; <= 48)
     uint32_t  max_stage_nodes;          // nodes of the cascade's largest stage
     uint32_t  gather_pairs;             // global-gather sweeps evaluate two stumps per step: 0 never, 1 when the wave holds one chunk, 2 always
-    uint32_t  round_away;               // window positions round(index * step) half away from zero (clod.cpp:1416) instead of lrint (:514)
+    uint32_t  pos_mode;                 // window_pos(): bit 0 = round half away from zero (clod.cpp:1416, :1034) instead of lrint (:514, :941); bit 1 = f64 product (block variant, :862)
     const UnitDev* skip_units;          // one per bitmap word of a frame: {scale, first window (flattened index, or ix0 | iy << 16), valid bits, word}
     uint32_t  n_skip_units;
     const UnitDev* skip_segs;           // one per recurrence domain (a window row, or a scale's whole list): {scale, first word, words, -}

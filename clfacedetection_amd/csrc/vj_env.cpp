@@ -84,6 +84,11 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     pl->prog = build_stage_program(c);
     const uint32_t skip_mode = p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW);
     pl->skip_mode = skip_mode;
+    // how a grid index becomes a pixel position (window_pos): bit 0 = round half away from zero, bit 1 = f64 product.
+    // precomputeWindows / the OpenCL path: lrint of the f32 product (clod.cpp:514); plain CPU loop: round() of it (:1416);
+    // block variant: lrint of the f64 product in its row loop (:941-942), round() of it in its per-stage lists (:1034)
+    pl->pos_mode = (p.flags & VJ_FLAG_GRID_F64) ? (skip_mode == VJ_FLAG_SKIP_LIST ? 3u : 2u)
+                                                : (skip_mode == VJ_FLAG_SKIP_ROW ? 1u : 0u);
     for (const auto& t : c.trees)
         if (t.n_nodes != 1) pl->trees = true;
     if (pl->trees) {
@@ -139,7 +144,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         if (!si.accepted || si.nx <= 0 || si.ny <= 0) continue;
         if ((p.scale_mask[0] | p.scale_mask[1]) != 0) {  // scale subset (multi-GPU sharding of one frame)
             const int k = si.scale_idx;
-            if (k >= 128 || !((p.scale_mask[k >> 6] >> (k & 63)) & 1ull)) continue;
+            if (k >= 127 || !((p.scale_mask[k >> 6] >> (k & 63)) & 1ull)) continue;   // bit 127 = VJ_SCALE_MASK_NONE
         }
         if (pl->scales.size() >= (size_t)MAX_SCALES) {
             set_error("more than %d scales", MAX_SCALES);
@@ -163,9 +168,9 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         int rc = build_node_table(c, W, si, table.data() + sd.table_first);
         if (rc) return rc;
         // furthest element any gather of this scale can touch, relative to frame start
-        // (positions are lrint(i * step), or round() half away from zero in VJ_FLAG_SKIP_ROW mode: one more covers both)
-        const uint32_t x_max = (uint32_t)std::lrint((double)((float)(si.nx - 1) * si.step)) + (skip_mode == VJ_FLAG_SKIP_ROW ? 1u : 0u);
-        const uint32_t y_max = (uint32_t)std::lrint((double)((float)(si.ny - 1) * si.step)) + (skip_mode == VJ_FLAG_SKIP_ROW ? 1u : 0u);
+        // (positions are lrint(i * step); the other roundings of window_pos differ by at most one: one more covers them)
+        const uint32_t x_max = (uint32_t)std::lrint((double)((float)(si.nx - 1) * si.step)) + (pl->pos_mode != 0u ? 1u : 0u);
+        const uint32_t y_max = (uint32_t)std::lrint((double)((float)(si.ny - 1) * si.step)) + (pl->pos_mode != 0u ? 1u : 0u);
         uint32_t reach = sd.e_lt + sd.e_dh + sd.e_dw;
         for (size_t k = 0; k < n_nodes; ++k) {
             const NodeRec& r = table[sd.table_first + k];
@@ -555,7 +560,7 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
     const float split = e->split_for(n_frames);
     const int small = small_frame_class(e, W, H, n_frames);
     vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
-                        p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW)) | ((uint32_t)small << 8), f2u(split));
+                        p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64)) | ((uint32_t)small << 8), f2u(split));
     auto it = e->plans.find(key);
     if (it != e->plans.end()) {
         it->second->last_used = ++e->plan_tick;
@@ -563,10 +568,10 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
         return VJ_OK;
     }
     // bounded cache: release the least recently used plans first (their kernels may still be running)
-    if ((int)e->plans.size() >= std::max(1, e->plan_cache_max)) {
+    if ((int)e->plans.size() >= std::max(2, e->plan_cache_max)) {
         HIP_TRY(hipStreamSynchronize(e->stream));
         if (e->stream2) HIP_TRY(hipStreamSynchronize(e->stream2));
-        while ((int)e->plans.size() >= std::max(1, e->plan_cache_max)) {
+        while ((int)e->plans.size() >= std::max(2, e->plan_cache_max)) {
             auto lru = e->plans.begin();
             for (auto i = e->plans.begin(); i != e->plans.end(); ++i)
                 if (i->second->last_used < lru->second->last_used) lru = i;
@@ -862,6 +867,10 @@ static int enqueue_prepare(vj_env* e, Lane* L, Plan* pl, const vj_image* frames,
         HIP_TRY(hipEventRecord(L->upload_done, copy_stream));
         HIP_TRY(hipStreamWaitEvent(e->stream, L->upload_done, 0));
     }
+    L->src_gray = d_gray;
+    L->src_frame_bytes = gray_frame_bytes;
+    L->src_stride = gray_stride;
+    L->src_channels = channels;
     HIP_TRY(hipEventRecord(L->ev[0], e->stream));
     if ((rc = enqueue_integral(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf, channels))) return rc;
     HIP_TRY(hipEventRecord(L->ev[1], e->stream));
@@ -934,7 +943,7 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
         ca.tile_finish = (uint32_t)e->tile_finish;
         ca.tile_ws_min = pl->sp_pad != 0u ? (uint32_t)e->tile_ws_min : 0u;   // no stump-parallel tables: wave-split to the end
         ca.tile_ws_max = (uint32_t)std::min(e->tile_ws_max, (int)TILE_WS_MAX_WINDOWS);
-        ca.round_away = pl->skip_mode == VJ_FLAG_SKIP_ROW ? 1u : 0u;
+        ca.pos_mode = pl->pos_mode;
         ca.gather_pairs = e->pairs_for(nf);
         ca.sp_tail_max = (uint32_t)std::max(0, std::min(e->sp_tail_max, 48));
         ca.max_stage_nodes = pl->max_stage_nodes;
@@ -1151,8 +1160,10 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
 }
 
 // Wait for the batch on lane L and decode it: detections appended to `dets` with frame numbers offset by f0.  When the
-// detection buffer overflowed it is grown and the cascade passes run again on the integral images, which are still in
-// place (a stream refuses a new batch while one is being redone: it is finished synchronously here).
+// detection buffer overflowed it is grown and the cascade passes run again — on the integral images still in place for a
+// blocking call, after recomputing them from the lane's frames for a stream lane (the two lanes of a vj_stream share
+// the environment's integral images, and the next batch's have replaced this one's by now).  The redo is ordered on the
+// environment's stream behind everything already queued, and finished synchronously here.
 static int finish_batch(vj_env* e, Lane* L, Plan* pl, int f0, int W, int H, const vj_params& p, std::vector<RawDet>* dets,
                         vj_counters* ctr, vj_timing* tm, std::vector<DetEntry>* raw_out = nullptr) {
     int rc;
@@ -1175,6 +1186,11 @@ static int finish_batch(vj_env* e, Lane* L, Plan* pl, int f0, int W, int H, cons
             while (want < n_det) want *= 2;
             if ((rc = L->d_det.ensure((size_t)want * sizeof(DetEntry)))) return rc;
             L->det_cap = want;
+            if (L->shared_integrals) {
+                HIP_TRY(hipEventRecord(L->ev[0], e->stream));
+                if ((rc = enqueue_integral(e, L->src_gray, L->src_frame_bytes, L->src_stride, W, H, L->nf, L->src_channels))) return rc;
+                HIP_TRY(hipEventRecord(L->ev[1], e->stream));
+            }
             if ((rc = enqueue_cascade(e, L, pl, W, H, p))) return rc;
             continue;
         }
@@ -1755,7 +1771,7 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         return VJ_OK;
     }
     if (strcmp(key, "plan_cache_max") == 0) {
-        e->plan_cache_max = std::max(1, atoi(value));
+        e->plan_cache_max = std::max(2, atoi(value));   // vj_detect_chain holds two plans at once
         return VJ_OK;
     }
     if (strcmp(key, "max_subbatch") == 0) {
@@ -1943,7 +1959,9 @@ int vj_grayscale(vj_env* e, const vj_image* image, uint8_t* gray, int gray_strid
         set_error("grayscale launch failed: %s", hipGetErrorString((hipError_t)hrc));
         return VJ_ERR_HIP;
     }
-    if ((size_t)gray_stride == pitch) {
+    if ((size_t)gray_stride == pitch && pitch == (size_t)w) {
+        // one block only when the device rows carry no padding: with w % 4 != 0 a block copy would write the pad bytes
+        // over the caller's row padding (caller data if `gray` is a view into a larger image) and past a tight last row
         HIP_TRY(hipMemcpyAsync(gray, e->d_out.p, pitch * (size_t)h, hipMemcpyDeviceToHost, e->stream));
         HIP_TRY(hipStreamSynchronize(e->stream));
         return VJ_OK;
@@ -2001,6 +2019,10 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
     }
     if ((p->flags & VJ_FLAG_SKIP_LIST) && (p->flags & VJ_FLAG_SKIP_ROW)) {
         set_error("VJ_FLAG_SKIP_LIST and VJ_FLAG_SKIP_ROW are two different loops of the reference: pick one");
+        return VJ_ERR_ARG;
+    }
+    if ((p->flags & VJ_FLAG_GRID_F64) && !(p->flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW))) {
+        set_error("VJ_FLAG_GRID_F64 names the block variant's two loops: combine it with VJ_FLAG_SKIP_ROW or VJ_FLAG_SKIP_LIST");
         return VJ_ERR_ARG;
     }
     int W, H, CH;
@@ -2380,7 +2402,8 @@ int vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int 
     if (!e || !c || !p || width <= 0 || height <= 0 || max_batch <= 0) return VJ_ERR_ARG;
     const int CH = channels <= 1 ? 1 : channels;
     if (CH != 1 && CH != 3 && CH != 4) return VJ_ERR_ARG;
-    if (!(p->scale_factor > 1.0f) || ((p->flags & VJ_FLAG_SKIP_LIST) && (p->flags & VJ_FLAG_SKIP_ROW))) return VJ_ERR_ARG;
+    if (!(p->scale_factor > 1.0f) || ((p->flags & VJ_FLAG_SKIP_LIST) && (p->flags & VJ_FLAG_SKIP_ROW)) ||
+        ((p->flags & VJ_FLAG_GRID_F64) && !(p->flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW)))) return VJ_ERR_ARG;
     if ((uint64_t)(width + 1) * (uint64_t)(height + 3) >= (1ull << 30)) {
         set_error("image too large");
         return VJ_ERR_LIMIT;
@@ -2411,8 +2434,10 @@ int vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int 
                   (unsigned long long)max_frames_per_subbatch(e, raw->plan.get()));
         return VJ_ERR_LIMIT;
     }
-    for (Lane& L : raw->lanes)
+    for (Lane& L : raw->lanes) {
         if ((rc = L.create())) return rc;
+        L.shared_integrals = true;
+    }
     HIP_TRY(hipStreamCreateWithFlags(&raw->copy, hipStreamNonBlocking));
     // every buffer at its final size now: nothing is (re)allocated while batches are in flight
     for (Lane& L : raw->lanes)

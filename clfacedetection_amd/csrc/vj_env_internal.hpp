@@ -85,7 +85,7 @@ struct Plan {
     // device copies
     DevBuf d_table, d_scales, d_stages, d_units, d_tile_units, d_sp_blocks, d_skip_units, d_skip_segs;
     // P2 skip modes (VJ_FLAG_SKIP_LIST / VJ_FLAG_SKIP_ROW): bitmap geometry and work lists of the two bitmap kernels
-    uint32_t skip_mode = 0, skip_frame_words = 0, n_skip_units = 0, n_skip_segs = 0;
+    uint32_t skip_mode = 0, pos_mode = 0, skip_frame_words = 0, n_skip_units = 0, n_skip_segs = 0;
     uint32_t n_sp_blocks = 0;
     int frames_q = 0;  // frames the ScaleDev.q_base/q_cap currently describe
     uint64_t last_used = 0;   // vj_env::plan_tick of the last call that used this plan (LRU eviction)
@@ -131,6 +131,13 @@ struct Lane {
     // the batch in flight (enqueue_batch -> finish_batch)
     bool pending = false;
     int nf = 0, first_frame = 0;
+    // where the integral kernels read this batch's frames (the lane's d_gray or the caller's device batch), so that a
+    // redo can recompute them: the lanes of a vj_stream share the environment's integral images, and by the time a
+    // batch turns out to have overflowed its detection buffer the next batch's integrals have replaced its own
+    const uint8_t* src_gray = nullptr;
+    size_t src_frame_bytes = 0;
+    int src_stride = 0, src_channels = 1;
+    bool shared_integrals = false;
     size_t n_pass = 0;
     int launches = 0;
     bool count = false;

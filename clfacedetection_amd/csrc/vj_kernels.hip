@@ -313,10 +313,17 @@ int launch_integral(const IntegralArgs& a, void* stream_) {
 // ====================================================================== cascade
 
 // Window position of grid index i: precomputeWindows' lrint(i * step) (clod.cpp:514, half to even; the contract of the
-// OpenCL path) or the plain CPU loop's round(i * step) (clod.cpp:1416, half away from zero; VJ_FLAG_SKIP_ROW).
-__device__ __forceinline__ uint32_t window_pos(uint32_t i, float step, uint32_t round_away) {
+// OpenCL path) or the plain CPU loop's round(i * step) (clod.cpp:1416, half away from zero; VJ_FLAG_SKIP_ROW).  The
+// block variant keeps `step` as a double (clod.cpp:862), so its product is the f64 one — exact, where the f32 product
+// is rounded to 24 bits first and may land on the other side of a half (VJ_FLAG_GRID_F64; lrint at :941-942, round()
+// at :1034).  pos_mode is wave-uniform: bit 0 = half away from zero, bit 1 = f64 product.
+__device__ __forceinline__ uint32_t window_pos(uint32_t i, float step, uint32_t pos_mode) {
+    if (pos_mode & 2u) {
+        const double v = (double)i * (double)step;
+        return (pos_mode & 1u) ? (uint32_t)round(v) : (uint32_t)__double2int_rn(v);
+    }
     const float v = (float)i * step;
-    return round_away != 0u ? (uint32_t)roundf(v) : (uint32_t)__float2int_rn(v);
+    return (pos_mode & 1u) ? (uint32_t)roundf(v) : (uint32_t)__float2int_rn(v);
 }
 
 // P2 skip modes: is grid window (ix, iy) of this scale one the reference's sequential loop visits?
@@ -960,8 +967,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
                     valid = window_visited(a, frame, scales[slot].skip_base, scales[slot].skip_wpr, nx, ix, iy);
                 QEntry en{0u, 0.0f};
                 if (valid) {
-                    const uint32_t x = window_pos(ix, step, a.round_away);
-                    const uint32_t y = window_pos(iy, step, a.round_away);
+                    const uint32_t x = window_pos(ix, step, a.pos_mode);
+                    const uint32_t y = window_pos(iy, step, a.pos_mode);
                     const uint32_t e = y * a.stride + x;
                     en.var = window_variance(sum_f, sq_f, e, e_lt, e_dw, e_dh, area, a.signed_mean != 0u);
                     en.off = frame_bytes + e * 4u;
@@ -1116,7 +1123,7 @@ __global__ __launch_bounds__(256) void skip_fail_bits(CascadeArgs a) {
             const size_t frame_off = (size_t)frame * a.frame_elems;
             const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
             const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
-            const uint32_t x = window_pos(ix, step, a.round_away), y = window_pos(iy, step, a.round_away);
+            const uint32_t x = window_pos(ix, step, a.pos_mode), y = window_pos(iy, step, a.pos_mode);
             const uint32_t e = y * a.stride + x;
             const float var = window_variance(sum_f, sq_f, e, scales[slot].e_lt, scales[slot].e_dw, scales[slot].e_dh, scales[slot].area,
                                               a.signed_mean != 0u);
@@ -1828,8 +1835,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
         const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
         // tile origin in the image: the first window's origin (same expression as below)
-        const uint32_t x0 = __builtin_amdgcn_readfirstlane(window_pos(ix0, step, a.round_away));
-        const uint32_t y0 = __builtin_amdgcn_readfirstlane(window_pos(iy0, step, a.round_away));
+        const uint32_t x0 = __builtin_amdgcn_readfirstlane(window_pos(ix0, step, a.pos_mode));
+        const uint32_t y0 = __builtin_amdgcn_readfirstlane(window_pos(iy0, step, a.pos_mode));
 
         __syncthreads();  // the previous tile's gathers are finished
         STAMP(0);
@@ -1900,8 +1907,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
             w_lo4[k] = 0u;
             w_q[k] = 0ull;
             if (w_valid[k]) {
-                const uint32_t x = window_pos(ix, step, a.round_away);
-                const uint32_t y = window_pos(iy, step, a.round_away);
+                const uint32_t x = window_pos(ix, step, a.pos_mode);
+                const uint32_t y = window_pos(iy, step, a.pos_mode);
                 // byte offset inside the tile (de-interleaved rows: window origins are even columns)
                 const uint32_t e = y * a.stride + x;
                 // unstaged blocks: byte offset in the batch sum image, as in cascade_pass

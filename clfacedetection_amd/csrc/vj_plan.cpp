@@ -48,6 +48,12 @@ std::vector<vj_scale_info> plan_scales(const vj_cascade& c, int W, int H, const 
             // lrint of an int / float quotient: round-half-even in the default mode
             si.nx = (int32_t)std::lrint((double)((float)(W - si.win_w) / si.step));
             si.ny = (int32_t)std::lrint((double)((float)(H - si.win_h) / si.step));
+            if (p.flags & VJ_FLAG_GRID_F64) {
+                // the block variant keeps `step` as a double (clod.cpp:862) and divides in f64 (:890-891)
+                const double stepd = std::max(2.0, (double)s);
+                si.nx = (int32_t)std::lrint((double)(uint32_t)(W - si.win_w) / stepd);
+                si.ny = (int32_t)std::lrint((double)(uint32_t)(H - si.win_h) / stepd);
+            }
             if (si.nx < 0) si.nx = 0;
             if (si.ny < 0) si.ny = 0;
             si.accepted = 1;
@@ -195,8 +201,8 @@ int vj_shard_scales(const vj_cascade* c, int width, int height, const vj_params*
     if (!c || !p || !scale_mask || width <= 0 || height <= 0 || n_ranks <= 0 || rank < 0 || rank >= n_ranks) return VJ_ERR_ARG;
     if (!(p->scale_factor > 1.0f)) return VJ_ERR_ARG;
     const std::vector<vj_scale_info> sc = plan_scales(*c, width, height, *p);
-    if (sc.size() > 128) {
-        set_error("more than 128 scales cannot be expressed as a scale mask");
+    if (sc.size() > 127) {
+        set_error("more than 127 scales cannot be expressed as a scale mask");
         return VJ_ERR_LIMIT;
     }
     std::vector<uint64_t> w(sc.size());
@@ -216,6 +222,8 @@ int vj_shard_scales(const vj_cascade* c, int width, int height, const vj_params*
         load[r] += w[k];
         if ((int)r == rank) scale_mask[k >> 6] |= 1ull << (k & 63);
     }
+    // an all-zero mask means "every scale" to vj_detect: a rank without a share says so explicitly
+    if ((scale_mask[0] | scale_mask[1]) == 0) scale_mask[1] = VJ_SCALE_MASK_NONE;
     return VJ_OK;
 }
 

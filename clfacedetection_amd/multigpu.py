@@ -15,7 +15,9 @@ from __future__ import annotations
 
 import numpy as np
 
-RECT_FIELDS = ("x", "y", "w", "h", "frame", "scale_idx")
+# every field of a result row travels: `weight` is the neighbour count of a grouped rectangle (min_neighbors != 0), an
+# integer-valued float (0 for raw candidates), so the gather can stay one int32 tensor
+RECT_FIELDS = ("x", "y", "w", "h", "frame", "scale_idx", "weight")
 
 
 def shard_frames(n_frames: int, rank: int, world: int) -> range:
@@ -50,12 +52,14 @@ def allgather_rects(rects: np.ndarray, device=None, group=None) -> np.ndarray:
     """All-gather variable-length detection lists; every rank returns the same array,
     sorted by (frame, scale_idx, y, x).  `rects` carries GLOBAL frame indices.
 
-    Two collectives: counts, then one padded int32 [max_count, 6] tensor per rank."""
+    Two collectives: counts, then one padded int32 [max_count, 7] tensor per rank."""
     import torch
     import torch.distributed as dist
 
     world = dist.get_world_size(group)
     dev = device if device is not None else torch.device("cpu")
+    if len(rects) and not np.array_equal(rects["weight"], np.rint(rects["weight"])):
+        raise ValueError("rectangle weights are neighbour counts: integers")
     mine = np.stack([rects[f].astype(np.int32) for f in RECT_FIELDS], axis=1) if len(rects) else \
         np.zeros((0, len(RECT_FIELDS)), np.int32)
     n = torch.tensor([len(mine)], dtype=torch.int64, device=dev)

@@ -2,7 +2,7 @@
 // OpenCL + CLUtil.  Call sites (main.cpp:53-57, 159-184) stay as they are: clodDetectObjects still takes the
 // CvHaarClassifierCascade* that cvLoad returned (main.cpp:36); it is converted once to the library's flat arrays
 // (vj_cascade_from_arrays) and cached by pointer.
-//   g++ -std=c++17 -I../../include clod_hip.cpp demo_main.cpp -L../../clfacedetection_amd -lvjhip
+//   g++ -std=c++17 -I../../include clod_hip.cpp clif_hip.cpp demo_main.cpp -L../../clfacedetection_amd -lvjhip
 #include "clod_hip.h"
 #include "vj.h"
 
@@ -11,8 +11,8 @@
 #include <map>
 #include <vector>
 
-struct CLODEnvironmentData {
-    vj_env* env = nullptr;
+struct CLODHipState {
+    vj_env* env = nullptr;                                             // the clif environment's: one device context for both
     std::map<const CvHaarClassifierCascade*, vj_cascade*> cascades;   // converted on first use
 };
 
@@ -22,21 +22,25 @@ struct CLODEnvironmentData {
 }
 
 CLODEnvironmentData* clodInitEnvironment(const cl_uint device_index) {                       // clod.h:61-62, clod.cpp:72-100
+    // the reference creates its clif environment on device 0 whatever device_index says (clod.cpp:76) and a second
+    // OpenCL context for the detector; here both halves share one environment on the device asked for
     auto* d = new CLODEnvironmentData();
-    const int rc = vj_env_create((int)device_index, &d->env);
-    if (rc) die("clodInitEnvironment", rc);
+    d->clif = clifInitEnvironment(device_index);
+    d->hip = new CLODHipState();
+    d->hip->env = clifHipEnv(d->clif);
     return d;
 }
 
-void clodReleaseEnvironment(CLODEnvironmentData* d) {                                          // clod.h:64-65
+void clodReleaseEnvironment(CLODFEnvironmentData* d) {                                         // clod.h:64-65
     if (!d) return;
-    for (auto& kv : d->cascades) vj_cascade_free(kv.second);
-    vj_env_destroy(d->env);
+    for (auto& kv : d->hip->cascades) vj_cascade_free(kv.second);
+    delete d->hip;
+    clifReleaseEnvironment(d->clif);
     delete d;
 }
 
 void clodInitBuffers(CLODEnvironmentData* d, const CvSize* s) {                                // clod.h:67-69
-    const int rc = vj_env_reserve(d->env, s->width, s->height, 1);
+    const int rc = vj_env_reserve(d->hip->env, s->width, s->height, 1);
     if (rc) die("clodInitBuffers", rc);
 }
 
@@ -83,7 +87,7 @@ CLODDetectObjectsResult clodDetectObjects(const IplImage* image, const CvHaarCla
                                           const CLODEnvironmentData* data, const CvSize min_window_size,
                                           const CvSize max_window_size, const cl_uint min_neighbors, const clod_flags flags,
                                           const cl_bool use_opencl) {                            // clod.h:72-81, clod.cpp:1339-1356
-    auto* d = const_cast<CLODEnvironmentData*>(data);   // the reference mutates its "const" environment too (clod.cpp:800)
+    CLODHipState* d = data->hip;                        // the reference mutates its "const" environment too (clod.cpp:800)
     vj_cascade*& vc = d->cascades[cascade];
     if (!vc) vc = convert(cascade);
     // the reference converts BGR -> gray on the host (cvCvtColor, clif.cpp:328); here the interleaved image goes in as it
@@ -97,8 +101,8 @@ CLODDetectObjectsResult clodDetectObjects(const IplImage* image, const CvHaarCla
     p.max_h = max_window_size.height;
     p.min_neighbors = min_neighbors;   // 0 in the demo (main.cpp:165); != 0: grouped as cv::groupRectangles does
     if (!use_opencl) {                 // the CPU variants' window sets (clod.cpp:1358-1499), still computed on the device
-        if (flags & CLOD_BLOCK_IMPLEMENTATION) { fprintf(stderr, "clodDetectObjects: the block variant is not implemented\n"); exit(1); }
         p.flags |= (flags & CLOD_PER_STAGE_ITERATIONS) ? VJ_FLAG_SKIP_LIST : VJ_FLAG_SKIP_ROW;
+        if (flags & CLOD_BLOCK_IMPLEMENTATION) p.flags |= VJ_FLAG_GRID_F64;   // clodDetectObjectsBlock: `step` is a double (clod.cpp:862)
     }
     vj_result r;
     const int rc = vj_detect(d->env, vc, &f, 1, &p, &r);

@@ -8,6 +8,7 @@
 #else
 #include "cv_compat_min.h"
 #endif
+#include "clif_hip.h"
 
 typedef unsigned int clod_flags;
 #define CLOD_PRECOMPUTE_FEATURES (2 << 0)
@@ -16,10 +17,13 @@ typedef unsigned int clod_flags;
 
 typedef struct CLODWeightedRect { CvRect rect; float weight; } CLODWeightedRect;
 typedef struct CLODDetectObjectsResult { CLODWeightedRect* matches; cl_uint match_count; } CLODDetectObjectsResult;
-typedef struct CLODEnvironmentData CLODEnvironmentData;
+typedef struct CLODFEnvironmentData {      /* clod.h:55-59: callers reach the clif environment through ->clif (main.cpp:54) */
+    CLIFEnvironmentData* clif;
+    struct CLODHipState* hip;              /* in place of the reference's CLDeviceEnvironment + cl_mem buffers */
+} CLODEnvironmentData;
 
 CLODEnvironmentData* clodInitEnvironment(const cl_uint device_index);
-void clodReleaseEnvironment(CLODEnvironmentData* data);
+void clodReleaseEnvironment(CLODFEnvironmentData* data);
 void clodInitBuffers(CLODEnvironmentData* data, const CvSize* image_size);
 void clodReleaseBuffers(CLODEnvironmentData* data);
 CLODDetectObjectsResult clodDetectObjects(const IplImage* image, const CvHaarClassifierCascade* cascade,

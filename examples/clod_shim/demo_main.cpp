@@ -1,6 +1,7 @@
 // The reference demo's call pattern (main.cpp:19-136, 159-184) against the shim: a CvHaarClassifierCascade in memory —
-// built here from a shipped .vjc because cvLoad needs OpenCV — a 640x480 frame, clodInitEnvironment / clodInitBuffers /
-// clodDetectObjects(..., CL_TRUE) and the two CPU-variant window sets, free().  Prints the match counts; exits 1 when the
+// built here from a shipped .vjc because cvLoad needs OpenCV — a 640x480 frame, clodInitEnvironment / clifInitBuffers / clodInitBuffers,
+// the clif* functions checked element by element (main.cpp:59-69), clodDetectObjects(..., CL_TRUE) and the four CPU-variant
+// window sets, free().  Prints the match counts; exits 1 when the
 // known answer of the survey's pin frame (2 raw detections) is missed.
 #include "clod_hip.h"
 #include "vj.h"
@@ -59,6 +60,81 @@ static bool load(const char* path, OwnedCascade* o) {
     return true;
 }
 
+// cvIntegral's definition, by the book, for the check below (main.cpp:59-69 compares one element of cvIntegral's
+// squared image with clifIntegral's and throws the result away; here every element of both images is compared)
+static void integral_by_definition(const unsigned char* g, int W, int H, std::vector<unsigned>& s, std::vector<unsigned long long>& q) {
+    s.assign((size_t)(W + 1) * (H + 1), 0u);
+    q.assign((size_t)(W + 1) * (H + 1), 0ull);
+    for (int y = 0; y < H; ++y) {
+        unsigned rs = 0;
+        unsigned long long rq = 0;
+        for (int x = 0; x < W; ++x) {
+            const unsigned v = g[(size_t)y * W + x];
+            rs += v;
+            rq += (unsigned long long)v * v;
+            s[(size_t)(y + 1) * (W + 1) + x + 1] = s[(size_t)y * (W + 1) + x + 1] + rs;
+            q[(size_t)(y + 1) * (W + 1) + x + 1] = q[(size_t)y * (W + 1) + x + 1] + rq;
+        }
+    }
+}
+
+static int check_clif(CLIFEnvironmentData* clif, const IplImage* gray, const std::vector<unsigned char>& px) {
+    const int W = gray->width, H = gray->height;
+    std::vector<unsigned> s;
+    std::vector<unsigned long long> q;
+    integral_by_definition(px.data(), W, H, s, q);
+    int ok = 1;
+    // clifIntegral, both branches of the reference: CL_TRUE leaves 64-bit integers in the CV_64FC1 matrix (main.cpp:69
+    // reads them through (unsigned long*)), CL_FALSE is cvIntegral: doubles (clod.cpp:837 reads ->data.db)
+    CLIFIntegralResult r = clifIntegral(gray, clif, CL_TRUE);                                   // main.cpp:68
+    ok = ok && r.image->rows == H + 1 && r.image->cols == W + 1 && r.image->type == CV_32SC1 && r.square_image->type == CV_64FC1;
+    for (int y = 0; y <= H && ok; ++y)
+        for (int x = 0; x <= W; ++x) {
+            const size_t k = (size_t)y * (W + 1) + x;
+            const unsigned sv = ((const unsigned*)(r.image->data.ptr + (size_t)y * r.image->step))[x];
+            const unsigned long long qv = ((const unsigned long long*)(r.square_image->data.ptr + (size_t)y * r.square_image->step))[x];
+            if (sv != s[k] || qv != q[k]) { ok = 0; break; }
+        }
+    printf("clifIntegral(CL_TRUE): sqsum[2000] = %llu, %s\n", ((unsigned long long*)r.square_image->data.db)[2000], ok ? "all elements equal" : "MISMATCH");
+    cvReleaseMat(&r.image);
+    cvReleaseMat(&r.square_image);
+    r = clifIntegral(gray, clif, CL_FALSE);
+    int ok2 = 1;
+    for (int y = 0; y <= H && ok2; ++y)
+        for (int x = 0; x <= W; ++x) {
+            const size_t k = (size_t)y * (W + 1) + x;
+            const int sv = ((const int*)(r.image->data.ptr + (size_t)y * r.image->step))[x];
+            const double qv = ((const double*)(r.square_image->data.ptr + (size_t)y * r.square_image->step))[x];
+            if ((unsigned)sv != s[k] || qv != (double)q[k]) { ok2 = 0; break; }
+        }
+    printf("clifIntegral(CL_FALSE): sqsum[2000] = %.1f, %s\n", r.square_image->data.db[2000], ok2 ? "all elements equal" : "MISMATCH");
+    cvReleaseMat(&r.image);
+    cvReleaseMat(&r.square_image);
+    // a BGR frame with B = G = R: any BGR2GRAY formula returns the gray value, so clifGrayscale gives the frame back and
+    // clifGrayscaleIntegral the same integrals (this is how the detector sees a frame: clod.cpp:360-369)
+    IplImage* bgr = cvCreateImage(cvSize(W, H), IPL_DEPTH_8U, 3);
+    for (int y = 0; y < H; ++y)
+        for (int x = 0; x < W; ++x)
+            for (int c = 0; c < 3; ++c) bgr->imageData[(size_t)y * bgr->widthStep + 3 * x + c] = (char)px[(size_t)y * W + x];
+    CLIFGrayscaleResult g = clifGrayscale(bgr, clif, CL_TRUE);
+    int ok3 = g.image->nChannels == 1 && g.image->width == W && g.image->height == H;
+    for (int y = 0; y < H && ok3; ++y)
+        ok3 = memcmp(g.image->imageData + (size_t)y * g.image->widthStep, px.data() + (size_t)y * W, (size_t)W) == 0;
+    cvReleaseImage(&g.image);
+    r = clifGrayscaleIntegral(bgr, clif, CL_FALSE);
+    for (int y = 0; y <= H && ok3; ++y)
+        for (int x = 0; x <= W; ++x) {
+            const size_t k = (size_t)y * (W + 1) + x;
+            if (((const unsigned*)(r.image->data.ptr + (size_t)y * r.image->step))[x] != s[k] ||
+                ((const double*)(r.square_image->data.ptr + (size_t)y * r.square_image->step))[x] != (double)q[k]) { ok3 = 0; break; }
+        }
+    printf("clifGrayscale + clifGrayscaleIntegral on the B=G=R frame: %s\n", ok3 ? "equal" : "MISMATCH");
+    cvReleaseMat(&r.image);
+    cvReleaseMat(&r.square_image);
+    cvReleaseImage(&bgr);
+    return ok && ok2 && ok3;
+}
+
 int main(int argc, char** argv) {
     const char* path = argc > 1 ? argv[1] : "clfacedetection_amd/data/haarcascade_frontalface_alt.vjc";
     OwnedCascade casc;
@@ -70,11 +146,17 @@ int main(int argc, char** argv) {
     IplImage img{1, IPL_DEPTH_8U, W, H, W, (char*)px.data()};
 
     CLODEnvironmentData* env = clodInitEnvironment(0);          // main.cpp:53
+    clifInitBuffers(env->clif, W, H, img.widthStep, 1);          // main.cpp:54
     CvSize size = cvSize(W, H);
     clodInitBuffers(env, &size);                                 // main.cpp:55
-    int ok = 1;
-    for (int variant = 0; variant < 3; ++variant) {              // main.cpp:72-97 runs the variants one after the other
-        const clod_flags flags = CLOD_PRECOMPUTE_FEATURES | (variant == 2 ? CLOD_PER_STAGE_ITERATIONS : 0);
+    int ok = check_clif(env->clif, &img, px);                    // main.cpp:59-69
+    // main.cpp:72-97 runs the variants one after the other: here the OpenCL route, then the four CPU loops
+    // (plain, per-stage lists, and the same two inside the block variant)
+    static const clod_flags kVariant[5] = {CLOD_PRECOMPUTE_FEATURES, CLOD_PRECOMPUTE_FEATURES, CLOD_PRECOMPUTE_FEATURES | CLOD_PER_STAGE_ITERATIONS,
+                                           CLOD_PRECOMPUTE_FEATURES | CLOD_BLOCK_IMPLEMENTATION,
+                                           CLOD_PRECOMPUTE_FEATURES | CLOD_BLOCK_IMPLEMENTATION | CLOD_PER_STAGE_ITERATIONS};
+    for (int variant = 0; variant < 5; ++variant) {
+        const clod_flags flags = kVariant[variant];
         CLODDetectObjectsResult r = clodDetectObjects(&img, &casc.c, env, cvSize(0, 0), cvSize(0, 0), 0, flags, variant == 0 ? CL_TRUE : CL_FALSE);
         printf("variant %d: %u matches", variant, r.match_count);
         for (cl_uint i = 0; i < r.match_count; ++i)
@@ -84,6 +166,7 @@ int main(int argc, char** argv) {
         free(r.matches);                 // main.cpp:183
     }
     clodReleaseBuffers(env);
+    clifReleaseBuffers(env->clif);
     clodReleaseEnvironment(env);
     printf(ok ? "clod shim demo: OK\n" : "clod shim demo: MISMATCH\n");
     return ok ? 0 : 1;

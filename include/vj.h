@@ -117,6 +117,11 @@ enum {
                                        round(index * step) — half away from zero (:1416) instead of
                                        precomputeWindows' lrint (:514) — and the next window of the ROW is
                                        skipped after a stage-0 reject (x_incr, :1430)                      */
+    VJ_FLAG_GRID_F64     = 1u << 4, /* with one of the two flags above: the same loop inside the block variant
+                                       (CLOD_BLOCK_IMPLEMENTATION, clod.cpp:821-1173), which keeps `step` as a
+                                       double (:862): grid ends lrint((W - w) / step) in f64 (:890-891) and
+                                       positions from the f64 product — lrint in the row loop (:941-942),
+                                       round() in the per-stage lists (:1034): a third and a fourth grid       */
 };
 
 typedef struct vj_params {
@@ -125,10 +130,13 @@ typedef struct vj_params {
     float    scale_factor;     /* reference hard-codes 1.1f (clod.cpp:1184)     */
     uint32_t min_neighbors;    /* 0 = raw candidates (the parity contract); else grouped */
     uint32_t flags;
-    uint64_t scale_mask[2];    /* bit k set = evaluate scale index k (k < 128); both
-                                  words 0 = every scale.  Shards one frame's scales
-                                  across GPUs; the reference has no counterpart.   */
+    uint64_t scale_mask[2];    /* bit k set = evaluate scale index k (k < 127); both
+                                  words 0 = every scale; bit 127 (VJ_SCALE_MASK_NONE
+                                  in word 1) = no scale at all: an empty share, the
+                                  call returns no rectangles.  Shards one frame's
+                                  scales across GPUs; no counterpart in the reference. */
 } vj_params;
+#define VJ_SCALE_MASK_NONE (1ull << 63)   /* in scale_mask[1]: what vj_shard_scales gives a rank that gets no scale */
 void vj_params_default(vj_params* p);   /* {0,0,0,0,1.1f,0,0,{0,0}} */
 
 /* ------------------------------------------------------ host scale planning */
@@ -351,7 +359,8 @@ int vj_group_rectangles(vj_rect* rects, uint32_t* count, int group_threshold, do
  * vj_shard_frames: batches with at least as many frames as ranks — contiguous blocks whose sizes differ by at most one.
  * vj_shard_scales: fewer frames than ranks (one large frame) — every rank integrates the frame and takes a subset of the
  * scales, longest-processing-time greedy on the window counts (ties to the lower rank); the result goes into
- * vj_params.scale_mask.                                                                                              */
+ * vj_params.scale_mask.  A rank that gets no scale (more ranks than scales) receives VJ_SCALE_MASK_NONE — an all-zero
+ * mask would mean "every scale" and duplicate the other ranks' rectangles.                                                                                            */
 int vj_shard_frames(int n_frames, int n_ranks, int rank, int* first, int* count);
 int vj_shard_scales(const vj_cascade* c, int width, int height, const vj_params* p, int n_ranks, int rank,
                     uint64_t scale_mask[2]);

@@ -340,7 +340,7 @@ class Oracle:
         linear = bool(np.all(c.stage_next == -1))
         if mode is None:
             mode = 0 if linear else 1
-        assert mode == 1 or linear, "modes 0, 2, 3 (the reference's own loops) are defined for linear cascades only"
+        assert mode == 1 or linear, "modes 0, 2, 3, 4, 5 (the reference's own loops) are defined for linear cascades only"
         out = np.zeros(cap, _RECT_DT)
         n_total = C.c_int(0)
         st = _OcStats()

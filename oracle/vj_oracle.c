@@ -306,7 +306,14 @@ static float stage_sum_for(const oc_cascade* c, const k_node* kn, const uint32_t
  *          (cl_uint)round(index * step) — half away from zero, not precomputeWindows' lrint (:1416 vs :514)
  *          — and `x_incr = exit_stage != 0 ? 1 : 2` (:1430) skips the next window of the ROW after a stage-0
  *          reject; every row starts at its first window.  Linear cascades.
- *          In modes 2 and 3 stage_entered[0] counts the windows actually visited (P2 of SURVEY.md §8a-8).
+ *  mode 4: the block variant's plain loop (clodDetectObjectsBlock without CLOD_PER_STAGE_ITERATIONS,
+ *          clod.cpp:936-1030): `step` stays a double (:862), so the grid ends are lrint of an f64 quotient
+ *          (:890-891) and the positions lrint of an f64 product (:941-942, half to even — not mode 3's round());
+ *          x_incr skip inside a row (:1009); the pixel sum is read through cl_uint* (:836, :944), so
+ *          signed_mean does not apply.
+ *  mode 5: the block variant's per-stage lists (clod.cpp:1031-1155): the same f64 grid with positions
+ *          round(index * step) (:1034, half away from zero) and the skip over the flattened list (:1131-1134).
+ *          In modes 2-5 stage_entered[0] counts the windows actually visited (P2 of SURVEY.md §8a-8).
  * Returns the number of rects written (at most cap; the true count is in *n_total). */
 int oc_detect(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride,
               int min_w, int min_h, int max_w, int max_h, float scale_factor,
@@ -331,10 +338,17 @@ int oc_detect(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride
             continue;
         sc.scale_idx = scale_index;
         precompute_nodes(c, current_scale, sc.area, iw, kn);
+        const double stepd = 2.0 > (double)current_scale ? 2.0 : (double)current_scale;   /* clod.cpp:862 */
+        if (mode == 4 || mode == 5) {
+            /* clod.cpp:890-891: (int - cl_uint) is unsigned, converted to double and divided by the double step */
+            sc.nx = (int)lrint((unsigned)(W - sc.win_w) / stepd);
+            sc.ny = (int)lrint((unsigned)(H - sc.win_h) / stepd);
+            signed_mean = 0;
+        }
         const size_t nwin = (size_t)(sc.nx > 0 ? sc.nx : 0) * (size_t)(sc.ny > 0 ? sc.ny : 0);
         if (nwin == 0) continue;
         k_window* a = (k_window*)malloc(sizeof(k_window) * nwin);
-        if (mode == 3) {
+        if (mode == 3 || mode == 4) {
             /* clod.cpp:1409-1432: x_incr is declared before the row loop, but every row's for-statement starts
              * again at start_point.x, so only the increments inside a row use it */
             st->windows += nwin;
@@ -342,8 +356,13 @@ int oc_detect(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride
             for (int y_index = 0; y_index < sc.ny; y_index++) {
                 for (int x_index = 0; x_index < sc.nx; x_index += (int)x_incr) {
                     k_window w;
-                    w.x = (uint32_t)round(x_index * sc.step);   /* int * float -> float, round(): half away */
-                    w.y = (uint32_t)round(y_index * sc.step);
+                    if (mode == 3) {
+                        w.x = (uint32_t)round(x_index * sc.step);   /* int * float -> float, round(): half away */
+                        w.y = (uint32_t)round(y_index * sc.step);
+                    } else {
+                        w.x = (uint32_t)lrint(x_index * stepd);     /* :941-942, int * double, half to even */
+                        w.y = (uint32_t)lrint(y_index * stepd);
+                    }
                     w.variance = compute_variance(sum, sqsum, iw, &sc, w.x, w.y, signed_mean);
                     w.offset = iw * w.y + w.x;
                     int exit_stage = 1;   /* runCascade, clod.cpp:736-787 */
@@ -365,22 +384,38 @@ int oc_detect(const oc_cascade* c, const uint8_t* gray, int W, int H, int stride
             free(a);
             continue;
         }
-        uint32_t n_in = precompute_windows(sum, sqsum, iw, &sc, signed_mean, a);
+        uint32_t n_in;
+        if (mode == 5) {
+            /* clod.cpp:1031-1067: the block variant fills its list itself, positions round(index * step) in f64 */
+            n_in = 0;
+            for (int y_index = 0; y_index < sc.ny; y_index++)
+                for (int x_index = 0; x_index < sc.nx; x_index++) {
+                    k_window* w = &a[n_in++];
+                    w->x = (uint32_t)round(x_index * stepd);
+                    w->y = (uint32_t)round(y_index * stepd);
+                    w->variance = compute_variance(sum, sqsum, iw, &sc, w->x, w->y, 0);
+                    w->offset = iw * w->y + w->x;
+                }
+            /* from here on it is the per-stage loop with the flattened skip (:1069-1145 == :681-734) */
+        } else {
+            n_in = precompute_windows(sum, sqsum, iw, &sc, signed_mean, a);
+        }
         st->windows += n_in;
-        if (mode == 0 || mode == 2) {
+        const int skip_list = (mode == 2 || mode == 5);
+        if (mode == 0 || skip_list) {
             k_window* b = (k_window*)malloc(sizeof(k_window) * nwin);
             uint32_t n_out = n_in;
             for (int stage = 0; stage < c->n_stages; ++stage) {
-                if (!(mode == 2 && stage == 0)) st->stage_entered[stage] += n_in;
+                if (!(skip_list && stage == 0)) st->stage_entered[stage] += n_in;
                 n_out = 0;
                 const float thr = c->stage_threshold[stage];
                 uint32_t subwindow_incr = 1;   /* runSubwindow, clod.cpp:700-733 */
                 for (uint32_t g = 0; g < n_in; g += subwindow_incr) {
                     float stage_sum = stage_sum_for(c, kn, ii, &a[g], stage, st);
                     subwindow_incr = 1;
-                    if (mode == 2 && stage == 0) st->stage_entered[0]++;
+                    if (skip_list && stage == 0) st->stage_entered[0]++;
                     if (stage_sum >= thr) b[n_out++] = a[g];
-                    else if (mode == 2 && stage == 0) subwindow_incr = 2;
+                    else if (skip_list && stage == 0) subwindow_incr = 2;
                 }
                 k_window* t = a; a = b; b = t;
                 n_in = n_out;

@@ -55,12 +55,66 @@ INTEGRAL_CASES = [  # (id, generator, seed, height, width)
 ]
 
 
+# BASELINE.json's configs at their full sizes (tests/golden/fullsize.json, tools/make_fullsize_golden.py): the oracle
+# runs once in the build container, the GPU suite compares whole results through rows_sha()
+FULLSIZE = {
+    "config3": {"cascade": "frontalface_alt", "frames": 64, "height": 1080, "width": 1920, "seed0": 1,
+                "kinds": ["noise", "smooth", "blocks"]},
+    "config4": {"cascade": "frontalface_alt_tree", "kind": "noise", "seed": 4096, "height": 4096, "width": 4096},
+    "config5_raw": {"cascade": "frontalface_alt2", "second": "eye", "frames": 256, "height": 720, "width": 1280,
+                    "seed0": 5001, "kinds": ["noise", "smooth", "blocks"]},
+    "config5_grouped": {"cascade": "frontalface_alt2", "second": "eye", "frames": 256, "height": 720, "width": 1280,
+                        "seed0": 5001, "kinds": ["faces", "noise", "smooth", "blocks"], "min_neighbors": 3},
+    # (id, cascade, generator, seed, height, width)
+    "opencv": [("cv_alt_pin_1080", "frontalface_alt", "xorshift", 12345, 1080, 1920),
+               ("cv_alt_smooth_1080", "frontalface_alt", "smooth", 2, 1080, 1920),
+               ("cv_alt_blocks_1080", "frontalface_alt", "blocks", 3, 1080, 1920),
+               ("cv_alt_faces_1080", "frontalface_alt", "faces", 4, 1080, 1920),
+               ("cv_alt_tree_noise_1080", "frontalface_alt_tree", "noise", 5, 1080, 1920),
+               ("cv_alt_tree_faces_1080", "frontalface_alt_tree", "faces", 6, 1080, 1920),
+               ("cv_alt2_faces_1080", "frontalface_alt2", "faces", 7, 1080, 1920),
+               ("cv_fullbody_smooth_1080", "fullbody", "smooth", 8, 1080, 1920)],
+    # (id, cascade, generator, seed, height, width, oracle mode): the CPU variants' window sets at 1080p
+    "modes": [(f"m{mode}_{kind}_1080", "frontalface_alt", kind, seed, 1080, 1920, mode)
+              for mode in (2, 3, 4, 5) for kind, seed in (("noise", 1), ("smooth", 2), ("faces", 4))],
+}
+
+
+def rows_sha(rects, keys=("scale_idx", "x", "y", "w", "h")) -> str:
+    """SHA-256 of the rows of a rectangle list as little-endian int32, in the order given (results are sorted by
+    (scale, y, x) on both sides).  `rects`: a structured array (fields `keys`) or a list of int tuples."""
+    if isinstance(rects, np.ndarray) and rects.dtype.names:
+        a = np.stack([rects[k].astype("<i4") for k in keys], 1) if len(rects) else np.zeros((0, len(keys)), "<i4")
+    else:
+        a = np.asarray(list(rects), "<i4").reshape(len(rects), -1) if len(rects) else np.zeros((0, 0), "<i4")
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
 def make_frame(generator: str, seed: int, h: int, w: int, oracle=None) -> np.ndarray:
     if generator == "xorshift":   # the survey's sequential generator lives in the oracle
         return oracle.xorshift_noise(seed, h, w)
     if generator == "white":
         return np.full((h, w), 255, np.uint8)
     return synth.frame(generator, seed, h, w)
+
+
+def block_grid_frame(transposed: bool = False) -> np.ndarray:
+    """A 900 x 300 (or 300 x 900) frame with a drawn face of 238 pixels at column (row) 650.  Scale 26 of a 20 x 20
+    cascade (s = 11.918..., window 238) puts grid index 55 on pixel 656 when the product index * step is the f32 one
+    (656.50 after rounding to 24 bits) and on 655 when it is the f64 one (655.4999...): the reference's block variant
+    (double step, clod.cpp:862) and its other loops then evaluate different windows over the face, and with
+    frontalface_alt they return different rectangles (x = 655 vs 656)."""
+    face = np.clip(synth.crude_face(238), 0, 255).astype(np.uint8)
+    if transposed:
+        img = synth.frame("smooth", 26, 900, 300).copy()
+        img[650:888, 20:258] = face
+    else:
+        img = synth.frame("smooth", 26, 300, 900).copy()
+        img[20:258, 650:888] = face
+    return img
+
+
+BLOCK_GRID_LIMITS = {"min_size": (230, 230), "max_size": (270, 270)}     # scales 26 and 27 only
 
 
 def sha(a: np.ndarray) -> str:

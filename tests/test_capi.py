@@ -74,10 +74,11 @@ def test_argument_errors(lib):
 
 def test_cpu_variants_never_compute_on_the_cpu():
     """use_opencl=False picks the WINDOW SET of the reference's CPU loops (skip modes), still on the device; the block
-    variant and clifIntegral's CPU branch (cvIntegral) are refused.  Nothing computes without an environment."""
+    variant selects its own two grids the same way; clifIntegral's CPU branch (cvIntegral) is refused.  Nothing computes
+    without an environment."""
     import numpy as np
     from clfacedetection_amd import CLOD_BLOCK_IMPLEMENTATION, clodDetectObjects, clifIntegral
-    with pytest.raises(VjError):
+    with pytest.raises(AttributeError):
         clodDetectObjects(np.zeros((40, 40), np.uint8), None, None, flags=CLOD_BLOCK_IMPLEMENTATION, use_opencl=False)
     with pytest.raises(AttributeError):   # no environment -> nothing to run on: there is no host evaluator to fall back to
         clodDetectObjects(np.zeros((40, 40), np.uint8), None, None, use_opencl=False)
@@ -112,3 +113,21 @@ def test_cascade_from_arrays_round_trip_and_validation(lib):
     with pytest.raises(VjError):
         Cascade.from_arrays(20, 20, bads, c.trees, c.nodes, c.alpha)
     assert lib.vj_cascade_from_arrays(20, 20, None, 0, None, 0, None, 0, None, 0, None) == 1
+
+
+def test_reference_shaped_shims_compile_and_fail_loudly_without_a_device(lib, tmp_path):
+    """examples/clod_shim: clod.h's five and clif.h's seven functions with the reference's argument lists, and a plain C
+    translation unit on include/vj.h, compile and link against libvjhip.so here; without a GPU they stop with the
+    library's "no CPU fallback" error instead of computing anywhere else (the GPU box runs them: tests/test_gpu_native.py)."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    libdir = os.path.join(root, "clfacedetection_amd")
+    exe = str(tmp_path / "clod_demo")
+    subprocess.run(["g++", "-std=c++17", "-Wall", "-Werror", "-Iinclude", "examples/clod_shim/clod_hip.cpp", "examples/clod_shim/clif_hip.cpp",
+                    "examples/clod_shim/demo_main.cpp", f"-L{libdir}", "-lvjhip", f"-Wl,-rpath,{libdir}", "-o", exe], cwd=root, check=True)
+    r = subprocess.run([exe], cwd=root, capture_output=True, text=True)
+    assert (r.returncode == 0 and "clod shim demo: OK" in r.stdout) or "no CPU fallback" in r.stderr
+    hdr = open(os.path.join(root, "examples", "clod_shim", "clif_hip.h")).read()
+    for name in ("clifInitEnvironment", "clifReleaseEnvironment", "clifInitBuffers", "clifReleaseBuffers", "clifGrayscale",
+                 "clifIntegral", "clifGrayscaleIntegral"):      # clif.h:42-73
+        assert name + "(" in hdr

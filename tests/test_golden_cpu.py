@@ -89,3 +89,54 @@ def test_group_fixture(oracle, cascades, g):
     x, y, w, h, _ = g["faces"][0]
     r2, _ = oracle.detect(a2, np.ascontiguousarray(img[y:y + h, x:x + w]))
     assert [[int(v) for v in (e["scale_idx"], e["x"], e["y"], e["w"], e["h"])] for e in r2] == g["inside"][0]
+
+
+FULL = json.load(open(os.path.join(G, "fullsize.json")))
+
+
+def test_fullsize_fixture_sample(oracle, cascades):
+    """tests/golden/fullsize.json (tools/make_fullsize_golden.py) on a sample that fits the CPU suite: the fixture names
+    the inputs cases.FULLSIZE describes, and the oracle reproduces a config-3 frame, a block-variant 1080p frame, an
+    OpenCV-profile 1080p frame and a config-5 frame with its regions."""
+    from cases import FULLSIZE, rows_sha
+    from clfacedetection_amd import synth
+    for name in ("config3", "config4", "config5_raw", "config5_grouped"):
+        for k, v in FULLSIZE[name].items():
+            assert FULL[name][k] == v, (name, k)
+    assert [[e[k] for k in ("id", "cascade", "generator", "seed", "height", "width")] for e in FULL["opencv"]] == \
+           [list(t) for t in FULLSIZE["opencv"]]
+    assert [[e[k] for k in ("id", "cascade", "generator", "seed", "height", "width", "mode")] for e in FULL["modes"]] == \
+           [list(t) for t in FULLSIZE["modes"]]
+    g = FULL["config3"]
+    _, a = cascades(g["cascade"])
+    f = 5
+    img = synth.frame(g["kinds"][f % 3], g["seed0"] + f, g["height"], g["width"])
+    r, st = oracle.detect(a, img)
+    assert (len(r), rows_sha(r)) == (g["n"][f], g["sha"][f]) and st["stage_entered"] == g["stage_entered_per_frame"][f]
+    assert sum(g["n"]) > 1000 and g["stage_entered"][0] == 64 * 6290352
+    assert [sum(col) for col in zip(*g["stage_entered_per_frame"])] == g["stage_entered"]
+    e = next(e for e in FULL["modes"] if e["id"] == "m4_faces_1080")
+    r, st = oracle.detect(a, make_frame(e["generator"], e["seed"], e["height"], e["width"], oracle), mode=4)
+    assert (len(r), rows_sha(r)) == (e["n"], e["sha"]) and st["stage_entered"] == e["stage_entered"]
+    e3 = next(e for e in FULL["modes"] if e["id"] == "m3_faces_1080")
+    assert e3["stage_entered"] != e["stage_entered"]          # the f64 grid is another grid at 1080p
+    e = next(e for e in FULL["opencv"] if e["id"] == "cv_alt_faces_1080")
+    r, st = oracle.detect_opencvlike(a, make_frame(e["generator"], e["seed"], e["height"], e["width"], oracle))
+    r = r[np.lexsort((r["x"], r["y"], r["scale_idx"]))]
+    assert (len(r), rows_sha(r)) == (e["n"], e["sha"]) and st["windows"] == e["windows"]
+    g = FULL["config5_grouped"]
+    _, a1 = cascades(g["cascade"])
+    _, a2 = cascades(g["second"])
+    f = 4          # a frame with drawn faces
+    img = synth.frame(g["kinds"][f % 4], g["seed0"] + f, g["height"], g["width"])
+    r, _ = oracle.detect(a1, img)
+    faces, wt = oracle.group_rectangles(np.stack([r[k] for k in ("x", "y", "w", "h")], 1), g["min_neighbors"])
+    rws = [(int(q[0]), int(q[1]), int(q[2]), int(q[3]), int(n)) for q, n in zip(faces, wt)]
+    assert (len(r), len(rws), rows_sha(rws)) == (g["n_raw"][f], g["n_faces"][f], g["sha_faces"][f]) and len(rws) > 0
+    inside = []
+    for i, (x, y, w, h, _) in enumerate(rws):
+        r2, _ = oracle.detect(a2, np.ascontiguousarray(img[y:y + h, x:x + w]))
+        inside += [(i, int(q["scale_idx"]), int(q["x"]), int(q["y"]), int(q["w"]), int(q["h"])) for q in r2]
+    assert (len(inside), rows_sha(inside)) == (g["n_second"][f], g["sha_second"][f])
+    g4 = FULL["config4"]
+    assert g4["windows"] == 53305712 == g4["stage_entered"][0] and sum(g4["n_per_scale"]) == g4["n"] and g4["n_scales"] == 56

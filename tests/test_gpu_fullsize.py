@@ -1,12 +1,38 @@
-"""BASELINE configs 3 and 5 at their FULL sizes (64 x 1080p; 256 x 720p, two cascades) through size-independent
-properties, plus the oracle on a bounded sample — the oracle needs ~2 s per 1080p frame, so it cannot check 64 of them
-inside the suite's budget."""
+"""BASELINE configs 2-5 at their FULL sizes (1080p frames; 64 x 1080p; 4096^2 with the stage tree; 256 x 720p, two
+cascades): WHOLE results against tests/golden/fullsize.json — per frame (or per scale) the rectangle count and the
+SHA-256 of the sorted rectangle rows, plus per-stage population totals, all produced by the oracle in the build
+container (tools/make_fullsize_golden.py; the oracle needs 1-10 s per frame, too slow to run on every frame here) —
+then size-independent properties, and the live oracle on a small sample as a check of the fixture itself."""
+import json
+import os
+
 import numpy as np
 import pytest
 
-from clfacedetection_amd import VJ_FLAG_COUNTERS, DeviceFrames, default_params, synth
+from cases import FULLSIZE, make_frame, rows_sha
+from clfacedetection_amd import (VJ_FLAG_COUNTERS, VJ_FLAG_GRID_F64, VJ_FLAG_SKIP_LIST, VJ_FLAG_SKIP_ROW, DeviceFrames,
+                                 default_params, synth)
 
 pytestmark = pytest.mark.gpu
+GOLD = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fullsize.json")))
+
+
+def spec_batch(spec):
+    return synth.batch(spec["frames"], spec["height"], spec["width"], seed0=spec["seed0"], kinds=tuple(spec["kinds"]))
+
+
+def check_spec(name):
+    """The fixture was generated for exactly the inputs cases.FULLSIZE names."""
+    g = GOLD[name]
+    for k, v in FULLSIZE[name].items():
+        assert g[k] == v, (name, k)
+    return g
+
+
+def per_frame(rects, n_frames, keys=("scale_idx", "x", "y", "w", "h")):
+    """[(count, sha)] per frame of a batch result (rects sorted by frame, scale, y, x)."""
+    cuts = np.searchsorted(rects["frame"], np.arange(n_frames + 1))
+    return [(int(cuts[f + 1] - cuts[f]), rows_sha(rects[cuts[f]:cuts[f + 1]], keys)) for f in range(n_frames)]
 
 
 def rows(rects, frame=None):
@@ -16,12 +42,16 @@ def rows(rects, frame=None):
 
 def test_config3_batch_of_64_1080p(env, oracle, cascades):
     import torch
-    c, a = cascades("frontalface_alt")
-    B, H, W = 64, 1080, 1920
-    frames = synth.batch(B, H, W, seed0=1)
+    g = check_spec("config3")
+    c, a = cascades(g["cascade"])
+    B, H, W = g["frames"], g["height"], g["width"]
+    frames = spec_batch(g)
     dev = torch.from_numpy(frames).cuda()
     df = DeviceFrames.from_torch(dev)
     full = env.detect(c, df, default_params(flags=VJ_FLAG_COUNTERS))
+    # every frame of the batch against the oracle's result (count + hash of the sorted rows), and the per-stage totals
+    assert per_frame(full.rects, B) == list(zip(g["n"], g["sha"]))
+    assert full.stage_entered == g["stage_entered"] and full.stump_evals == g["stump_evals"]
     # counters: the candidate-window count of the metric, monotone per-stage populations, consistent totals
     assert full.windows == B * 6290352 == full.stage_entered[0]
     assert all(x >= y for x, y in zip(full.stage_entered, full.stage_entered[1:]))
@@ -44,22 +74,43 @@ def test_config3_batch_of_64_1080p(env, oracle, cascades):
     both = np.concatenate([ev, od])
     both = both[np.lexsort((both["x"], both["y"], both["scale_idx"], both["frame"]))]
     assert np.array_equal(both, full.rects)
-    # the oracle on a sample of the batch
-    for f in (0, 37):
-        ro, st = oracle.detect(a, frames[f])
-        assert rows(full.rects, f) == rows(ro)
+    # the live oracle on one frame: the fixture is what the oracle gives here too
+    ro, st = oracle.detect(a, frames[37])
+    assert rows(full.rects, 37) == rows(ro) and (len(ro), rows_sha(ro)) == (g["n"][37], g["sha"][37])
+    assert st["stage_entered"] == g["stage_entered_per_frame"][37]
+    # per-frame stage populations: eight frames one at a time
+    for f in range(0, B, 8):
+        assert env.detect(c, frames[f], default_params(flags=VJ_FLAG_COUNTERS)).stage_entered == g["stage_entered_per_frame"][f]
+
+
+def second_leg_per_frame(r1, r2, n_frames):
+    """[(count, sha)] per FRAME of the second cascade's result: rows (region index within the frame, scale, x, y, w, h),
+    regions in the first result's order — the layout tools/make_fullsize_golden.py hashes."""
+    cuts1 = np.searchsorted(r1.rects["frame"], np.arange(n_frames + 1))      # first region of every frame
+    cuts2 = np.searchsorted(r2.rects["frame"], cuts1)                         # r2's "frame" = region index
+    out = []
+    for f in range(n_frames):
+        q = r2.rects[cuts2[f]:cuts2[f + 1]]
+        rws = [(int(e["frame"]) - int(cuts1[f]), int(e["scale_idx"]), int(e["x"]), int(e["y"]), int(e["w"]), int(e["h"])) for e in q]
+        out.append((len(rws), rows_sha(rws)))
+    return out
 
 
 def test_config5_256_frames_two_cascades(env, oracle, cascades):
     import torch
-    face, face_a = cascades("frontalface_alt2")
-    eye, eye_a = cascades("eye")
-    B, H, W = 256, 720, 1280
-    frames = synth.batch(B, H, W, seed0=5001)
+    g = check_spec("config5_raw")
+    face, face_a = cascades(g["cascade"])
+    eye, eye_a = cascades(g["second"])
+    B, H, W = g["frames"], g["height"], g["width"]
+    frames = spec_batch(g)
     dev = torch.from_numpy(frames).cuda()
     df = DeviceFrames.from_torch(dev)
     r1, r2 = env.detect_chain(face, eye, df, default_params(flags=VJ_FLAG_COUNTERS), default_params(flags=VJ_FLAG_COUNTERS))
     assert r1.windows == B * 2700015 and len(r1.rects) > 100
+    # both legs, every frame, against the oracle's results: faces per frame, eyes inside every raw candidate per frame
+    assert per_frame(r1.rects, B) == list(zip(g["n"], g["sha"])) and r1.stage_entered == g["stage_entered"]
+    assert second_leg_per_frame(r1, r2, B) == list(zip(g["n_second"], g["sha_second"]))
+    assert r2.stage_entered == g["stage_entered_second"] and r2.windows == g["windows_second"]
     # first leg = vj_detect; both legs = the same chain on four sub-batches of 64 frames
     assert np.array_equal(env.detect(face, df).rects, r1.rects)
     n1 = n2 = 0
@@ -96,13 +147,19 @@ def test_config5_256_frames_eyes_inside_grouped_faces(env, oracle, cascades):
     device equals grouping on the host at the full batch size; the chain on sub-batches gives the same; the second leg
     equals the host hand-off and the oracle on sub-images."""
     import torch
-    face, face_a = cascades("frontalface_alt2")
-    eye, eye_a = cascades("eye")
-    B, H, W = 256, 720, 1280
-    frames = synth.batch(B, H, W, seed0=5001, kinds=("faces", "noise", "smooth", "blocks"))
+    g = check_spec("config5_grouped")
+    face, face_a = cascades(g["cascade"])
+    eye, eye_a = cascades(g["second"])
+    B, H, W = g["frames"], g["height"], g["width"]
+    frames = spec_batch(g)
     df = DeviceFrames.from_torch(torch.from_numpy(frames).cuda())
-    p1 = default_params(min_neighbors=3)
+    p1 = default_params(min_neighbors=g["min_neighbors"])
     r1, r2 = env.detect_chain(face, eye, df, p1)
+    # every frame against the oracle: its grouping of its own candidates (x, y, w, h, neighbours), eyes inside every face
+    assert per_frame(r1.rects, B, ("x", "y", "w", "h", "weight")) == list(zip(g["n_faces"], g["sha_faces"]))
+    assert second_leg_per_frame(r1, r2, B) == list(zip(g["n_second"], g["sha_second"]))
+    raw = env.detect(face, df)
+    assert [n for n, _ in per_frame(raw.rects, B)] == g["n_raw"]
     assert np.array_equal(env.detect(face, df, p1).rects, r1.rects)
     assert len(r1.rects) >= 64 * 3 and len(r2.rects) > 0
     n1 = 0
@@ -131,3 +188,56 @@ def test_config5_256_frames_eyes_inside_grouped_faces(env, oracle, cascades):
     mine = r1.rects[r1.rects["frame"] == 4]
     assert [(int(r["x"]), int(r["y"]), int(r["w"]), int(r["h"]), int(r["weight"])) for r in mine] == \
            [(int(q[0]), int(q[1]), int(q[2]), int(q[3]), int(n)) for q, n in zip(g, w)]
+
+
+def test_config4_every_scale_of_the_4096_frame(env, cascades):
+    """BASELINE config 4 (one 4096 x 4096 frame, frontalface_alt_tree, 56 scales, 53,305,712 windows): the whole result,
+    scale by scale, against the oracle's (tests/golden/fullsize.json) — tiles, in-tile chains, grid pass and the queue
+    passes of both chains of the stage tree all take part at this size."""
+    g = check_spec("config4")
+    c, _ = cascades(g["cascade"])
+    img = synth.frame(g["kind"], g["seed"], g["height"], g["width"])
+    r = env.detect(c, img, default_params(flags=VJ_FLAG_COUNTERS))
+    assert len(c.plan_scales(g["width"], g["height"])) == g["n_scales"]
+    per = [r.rects[r.rects["scale_idx"] == k] for k in range(g["n_scales"])]
+    assert [len(p) for p in per] == g["n_per_scale"]
+    assert [rows_sha(p) for p in per] == g["sha_per_scale"]
+    assert (len(r.rects), rows_sha(r.rects)) == (g["n"], g["sha"])
+    assert r.windows == g["windows"] and r.stage_entered == g["stage_entered"] and r.stump_evals == g["stump_evals"]
+    # two frames in one call (the tile / queue machinery with more than one frame per part)
+    r2 = env.detect(c, np.stack([img, img]))
+    assert per_frame(r2.rects, 2) == [(g["n"], g["sha"])] * 2
+
+
+@pytest.mark.parametrize("g", GOLD["opencv"], ids=lambda d: d["id"])
+def test_opencv_profile_at_1080p(env, oracle, cascades, g):
+    """vj_detect_opencv on 1080p frames (the pinned xorshift frame, drawn faces, a stage tree, two-node trees, tilted
+    features) against oc_detect_opencvlike's results frozen in tests/golden/fullsize.json."""
+    assert [g[k] for k in ("id", "cascade", "generator", "seed", "height", "width")] in [list(t) for t in FULLSIZE["opencv"]]
+    c, _ = cascades(g["cascade"])
+    img = make_frame(g["generator"], g["seed"], g["height"], g["width"], oracle)
+    r = env.detect_opencv(c, img, flags=VJ_FLAG_COUNTERS)
+    q = r.rects[np.lexsort((r.rects["x"], r.rects["y"], r.rects["scale_idx"]))]
+    assert (len(q), rows_sha(q)) == (g["n"], g["sha"])
+    assert r.windows == g["windows"] and r.stage_entered == g["stage_entered"]
+    # the uncounted kernels, inside a batch
+    rb = env.detect_opencv(c, np.stack([img, img, img]))
+    for f in range(3):
+        qf = rb.rects[rb.rects["frame"] == f]
+        qf = qf[np.lexsort((qf["x"], qf["y"], qf["scale_idx"]))]
+        assert (len(qf), rows_sha(qf)) == (g["n"], g["sha"])
+
+
+MODE_FLAGS = {2: VJ_FLAG_SKIP_LIST, 3: VJ_FLAG_SKIP_ROW, 4: VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64, 5: VJ_FLAG_SKIP_LIST | VJ_FLAG_GRID_F64}
+
+
+@pytest.mark.parametrize("g", GOLD["modes"], ids=lambda d: d["id"])
+def test_cpu_variant_window_sets_at_1080p(env, oracle, cascades, g):
+    """The four CPU loops of the reference (oracle modes 2-5) on 1080p frames: at this size the block variant's f64
+    grid differs from the f32 one in two scales (index 55 of scale 26 and index 50 of scale 27 land on 655 instead of
+    656), so modes 4 / 5 are not modes 3 / 2 here."""
+    assert [g[k] for k in ("id", "cascade", "generator", "seed", "height", "width", "mode")] in [list(t) for t in FULLSIZE["modes"]]
+    c, _ = cascades(g["cascade"])
+    img = make_frame(g["generator"], g["seed"], g["height"], g["width"], oracle)
+    r = env.detect(c, img, default_params(flags=VJ_FLAG_COUNTERS | MODE_FLAGS[g["mode"]]))
+    assert (len(r.rects), rows_sha(r.rects)) == (g["n"], g["sha"]) and r.stage_entered == g["stage_entered"]

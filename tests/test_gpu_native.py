@@ -27,13 +27,16 @@ def test_c_translation_unit_uses_the_header(lib, tmp_path):
 
 
 def test_clod_shim_keeps_the_reference_call_sites(lib, tmp_path):
-    """clodInitEnvironment / clodInitBuffers / clodDetectObjects(IplImage*, CvHaarClassifierCascade*, ...) / free() over the
-    library (examples/clod_shim): the OpenCL route and the two CPU-variant window sets on the survey's pin frame."""
+    """clodInitEnvironment / clifInitBuffers / clodInitBuffers / clifIntegral / clifGrayscale / clifGrayscaleIntegral /
+    clodDetectObjects(IplImage*, CvHaarClassifierCascade*, ...) / free() over the library (examples/clod_shim): both integral
+    images element by element, then the OpenCL route and the four CPU-variant window sets on the survey's pin frame."""
     exe = str(tmp_path / "clod_demo")
-    _run(["g++", "-std=c++17", "-Wall", "-Iinclude", "examples/clod_shim/clod_hip.cpp", "examples/clod_shim/demo_main.cpp", f"-L{LIBDIR}",
+    _run(["g++", "-std=c++17", "-Wall", "-Iinclude", "examples/clod_shim/clod_hip.cpp", "examples/clod_shim/clif_hip.cpp", "examples/clod_shim/demo_main.cpp",
+          f"-L{LIBDIR}",
           "-lvjhip", f"-Wl,-rpath,{LIBDIR}", "-o", exe])
     out = _run([exe])
-    assert "clod shim demo: OK" in out and out.count("2 matches") == 3
+    assert "clod shim demo: OK" in out and out.count("2 matches") == 5 and out.count("all elements equal") == 2
+    assert "clifGrayscaleIntegral on the B=G=R frame: equal" in out
 
 
 def test_native_multi_gpu_host_with_rccl(lib, tmp_path):

@@ -54,6 +54,30 @@ def test_native_shard_helpers_agree_with_the_python_ones(lib, cascades):
             assert sorted(k for p in parts for k in p) == list(range(len(counts)))
 
 
+def test_a_rank_without_a_share_gets_the_explicit_empty_mask(lib, cascades):
+    """More ranks than scales: an all-zero vj_params.scale_mask means EVERY scale, so a rank that receives nothing must
+    not be handed one — vj_shard_scales returns VJ_SCALE_MASK_NONE (bit 127), which vj_detect answers with no rectangles,
+    and default_params(scales=[]) builds the same mask."""
+    import ctypes as C
+    from clfacedetection_amd import default_params
+    c, _ = cascades("frontalface_alt")
+    n = len(c.plan_scales(64, 48))
+    assert 0 < n < 12
+    world = 16
+    shares = []
+    for r in range(world):
+        m = (C.c_uint64 * 2)()
+        assert lib.vj_shard_scales(c._h, 64, 48, C.byref(default_params()), world, r, m) == 0
+        assert (m[0] | m[1]) != 0                                   # never "every scale"
+        shares.append(None if (m[0], m[1]) == (0, 1 << 63) else [k for k in range(127) if (m[k >> 6] >> (k & 63)) & 1])
+    assert shares.count(None) == world - n and sorted(k for s in shares if s for k in s) == list(range(n))
+    assert c.shard_scales(64, 48, world - 1, world) == []
+    p = default_params(scales=[])
+    assert (p.scale_mask[0], p.scale_mask[1]) == (0, 1 << 63)
+    with pytest.raises(ValueError):
+        default_params(scales=[127])
+
+
 def _worker(rank, world, port, mode, q):
     import sys
     import torch.distributed as dist
@@ -78,7 +102,7 @@ def _worker(rank, world, port, mode, q):
         r, _ = o.detect(a, frames[f])
         for d in r:
             if my_scales is None or int(d["scale_idx"]) in my_scales:
-                rows.append((d["x"], d["y"], d["w"], d["h"], 0.0, f, d["scale_idx"]))
+                rows.append((d["x"], d["y"], d["w"], d["h"], float(3 + (int(d["x"]) + int(d["y"])) % 5), f, d["scale_idx"]))   # a neighbour count
     mine = np.array(rows, RECT_DTYPE) if rows else np.zeros(0, RECT_DTYPE)
     allr = multigpu.allgather_rects(mine)
     q.put((rank, allr.tolist(), len(mine)))
@@ -108,8 +132,8 @@ def test_two_ranks_reproduce_single_process(oracle, cascades, mode):
     want = []
     for f in range(n_frames):
         r, _ = oracle.detect(a, frames[f])
-        want += [(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), f, int(d["scale_idx"])) for d in r]
+        want += [(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), float(3 + (int(d["x"]) + int(d["y"])) % 5), f, int(d["scale_idx"])) for d in r]
     assert len(want) > 0
     for rank, allr, n_mine in got:
-        assert [(x, y, w, h, fr, sc) for (x, y, w, h, _, fr, sc) in allr] == want
+        assert [(x, y, w, h, wt, fr, sc) for (x, y, w, h, wt, fr, sc) in allr] == want      # weights (neighbour counts) travel too
     assert sum(g[2] for g in got) == len(want)      # shards are disjoint

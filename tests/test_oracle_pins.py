@@ -10,6 +10,7 @@ not written down in the survey; seed 12345 reproduces every recorded figure exac
 """
 import os
 
+import numpy as np
 import pytest
 
 from cases import make_frame
@@ -137,3 +138,28 @@ def test_bgr2gray_known_answers(oracle):
     assert np.array_equal(oracle.bgr2gray(img[..., :3]), want.astype(np.uint8))
     g = rng.integers(0, 256, (9, 11), dtype=np.uint8)                          # B = G = R returns the gray value exactly
     assert np.array_equal(oracle.bgr2gray(np.repeat(g[..., None], 3, 2)), g)
+
+
+def test_block_variant_modes_are_their_own_grids(oracle):
+    """Oracle modes 4 / 5 restate clodDetectObjectsBlock (clod.cpp:821-1173), whose `step` is a double (:862).  Where no
+    product index * step comes within an f32 rounding of a half they visit the windows of modes 3 / 2; on the crafted
+    frame they do not (cases.block_grid_frame), and the rectangles differ by one column."""
+    import os
+    from cases import BLOCK_GRID_LIMITS, block_grid_frame
+    from clfacedetection_amd import synth
+    from clfacedetection_amd.api import DATA_DIR
+    from oracle.oracle import load_vjc
+    a = load_vjc(os.path.join(DATA_DIR, "haarcascade_frontalface_alt.vjc"))
+    img = synth.frame("smooth", 3, 240, 320)
+    for f32_mode, f64_mode in ((3, 4), (2, 5)):
+        r32, s32 = oracle.detect(a, img, mode=f32_mode)
+        r64, s64 = oracle.detect(a, img, mode=f64_mode)
+        assert np.array_equal(r32, r64) and s32 == s64
+    for transposed in (False, True):
+        img = block_grid_frame(transposed)
+        k = "y" if transposed else "x"
+        for f32_mode, f64_mode in ((3, 4), (2, 5)):
+            r32, _ = oracle.detect(a, img, mode=f32_mode, **BLOCK_GRID_LIMITS)
+            r64, _ = oracle.detect(a, img, mode=f64_mode, **BLOCK_GRID_LIMITS)
+            c32, c64 = r32[r32["scale_idx"] == 26][k], r64[r64["scale_idx"] == 26][k]
+            assert 656 in c32 and 655 not in c32 and 655 in c64 and 656 not in c64

@@ -1,0 +1,176 @@
+"""Regenerates tests/golden/fullsize.json from the CPU oracle (run in the build container; minutes on 8 cores).
+
+BASELINE.json's configs at their FULL sizes are too slow for the oracle inside the GPU suite (1-10 s per frame), so
+this script runs it once here and commits what the suite needs to compare WHOLE results: per frame (or per scale)
+the number of rectangles and a SHA-256 of the sorted rectangle rows, plus the per-stage population totals.  Frames are
+regenerated from their seeds on the GPU box (clfacedetection_amd/synth.py); nothing but hashes and counts is stored.
+
+  python tools/make_fullsize_golden.py                  # everything
+  python tools/make_fullsize_golden.py config3 modes    # only these sections (the others are kept from the file)
+
+Sections: config3 (64 x 1080p, frontalface_alt), modes (1080p frames under the CPU variants' window sets),
+config4 (4096^2, frontalface_alt_tree, all 56 scales), config5_raw / config5_grouped (256 x 720p, frontalface_alt2 ->
+eye on every raw candidate / on every grouped face), opencv (1080p frames through oc_detect_opencvlike).
+Hash convention: tests/cases.py rows_sha().
+"""
+import json
+import os
+import sys
+import time
+from multiprocessing import Pool
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from cases import FULLSIZE, make_frame, rows_sha  # noqa: E402
+from clfacedetection_amd import synth  # noqa: E402
+from clfacedetection_amd.api import DATA_DIR  # noqa: E402
+from oracle.oracle import Oracle, load_vjc  # noqa: E402
+
+OUT = os.path.join(ROOT, "tests", "golden", "fullsize.json")
+_o = None
+_c = {}
+
+
+def orc():
+    global _o
+    if _o is None:
+        _o = Oracle()
+    return _o
+
+
+def casc(name):
+    if name not in _c:
+        _c[name] = load_vjc(os.path.join(DATA_DIR, f"haarcascade_{name}.vjc"))
+    return _c[name]
+
+
+def batch_frame(spec, f):
+    kinds = spec["kinds"]
+    return synth.frame(kinds[f % len(kinds)], spec["seed0"] + f, spec["height"], spec["width"])
+
+
+def add(a, b):
+    return [x + y for x, y in zip(a, b)] if a else list(b)
+
+
+# ------------------------------------------------------------------ workers (one frame each)
+def w_detect(args):
+    spec, f, mode = args
+    img = batch_frame(spec, f)
+    r, st = orc().detect(casc(spec["cascade"]), img, mode=mode)
+    return f, len(r), rows_sha(r), st
+
+
+def w_chain_raw(args):
+    spec, f = args
+    img = batch_frame(spec, f)
+    r, st = orc().detect(casc(spec["cascade"]), img)
+    rows2, entered2, evals2 = [], [], 0
+    for i, q in enumerate(r):
+        x, y, w, h = int(q["x"]), int(q["y"]), int(q["w"]), int(q["h"])
+        r2, st2 = orc().detect(casc(spec["second"]), np.ascontiguousarray(img[y:y + h, x:x + w]))
+        rows2 += [(i, int(e["scale_idx"]), int(e["x"]), int(e["y"]), int(e["w"]), int(e["h"])) for e in r2]
+        entered2 = add(entered2, st2["stage_entered"])
+        evals2 += st2["windows"]
+    return f, len(r), rows_sha(r), st, len(rows2), rows_sha(rows2), entered2, evals2
+
+
+def w_chain_grouped(args):
+    spec, f = args
+    img = batch_frame(spec, f)
+    r, st = orc().detect(casc(spec["cascade"]), img)
+    xywh = np.stack([r[k] for k in ("x", "y", "w", "h")], 1) if len(r) else np.zeros((0, 4), np.int32)
+    g, wt = orc().group_rectangles(xywh, spec["min_neighbors"])
+    faces = [(int(q[0]), int(q[1]), int(q[2]), int(q[3]), int(n)) for q, n in zip(g, wt)]
+    rows2 = []
+    for i, (x, y, w, h, _) in enumerate(faces):
+        r2, _ = orc().detect(casc(spec["second"]), np.ascontiguousarray(img[y:y + h, x:x + w]))
+        rows2 += [(i, int(e["scale_idx"]), int(e["x"]), int(e["y"]), int(e["w"]), int(e["h"])) for e in r2]
+    return f, len(r), len(faces), rows_sha(faces), len(rows2), rows_sha(rows2)
+
+
+def w_opencv(case):
+    cid, cname, gen, seed, h, w = case
+    img = make_frame(gen, seed, h, w, orc())
+    r, st = orc().detect_opencvlike(casc(cname), img)
+    r = r[np.lexsort((r["x"], r["y"], r["scale_idx"]))]
+    return {"id": cid, "cascade": cname, "generator": gen, "seed": seed, "height": h, "width": w, "n": len(r),
+            "sha": rows_sha(r), "windows": st["windows"], "stage_entered": st["stage_entered"]}
+
+
+def w_mode(case):
+    cid, cname, gen, seed, h, w, mode = case
+    img = make_frame(gen, seed, h, w, orc())
+    r, st = orc().detect(casc(cname), img, mode=mode)
+    return {"id": cid, "cascade": cname, "generator": gen, "seed": seed, "height": h, "width": w, "mode": mode,
+            "n": len(r), "sha": rows_sha(r), "stage_entered": st["stage_entered"]}
+
+
+# ------------------------------------------------------------------ sections
+def sec_config3(pool):
+    spec = FULLSIZE["config3"]
+    res = sorted(pool.map(w_detect, [(spec, f, None) for f in range(spec["frames"])], chunksize=1))
+    tot, evals = [], 0
+    for _, _, _, st in res:
+        tot = add(tot, st["stage_entered"])
+        evals += st["stump_evals"]
+    return {**spec, "n": [r[1] for r in res], "sha": [r[2] for r in res], "stage_entered": tot, "stump_evals": evals,
+            "stage_entered_per_frame": [r[3]["stage_entered"] for r in res]}
+
+
+def sec_config4(pool):
+    spec = FULLSIZE["config4"]
+    img = synth.frame(spec["kind"], spec["seed"], spec["height"], spec["width"])
+    r, st = orc().detect(casc(spec["cascade"]), img)
+    n_scales = len(orc().plan_scales(casc(spec["cascade"]), spec["width"], spec["height"]))
+    per = [r[r["scale_idx"] == k] for k in range(n_scales)]
+    return {**spec, "n_scales": n_scales, "n": len(r), "sha": rows_sha(r), "n_per_scale": [len(p) for p in per],
+            "sha_per_scale": [rows_sha(p) for p in per], "windows": st["windows"], "stump_evals": st["stump_evals"],
+            "stage_entered": st["stage_entered"]}
+
+
+def sec_config5_raw(pool):
+    spec = FULLSIZE["config5_raw"]
+    res = sorted(pool.map(w_chain_raw, [(spec, f) for f in range(spec["frames"])], chunksize=1))
+    t1, t2, w2 = [], [], 0
+    for r in res:
+        t1 = add(t1, r[3]["stage_entered"])
+        t2 = add(t2, r[6]) if r[6] else t2
+        w2 += r[7]
+    return {**spec, "n": [r[1] for r in res], "sha": [r[2] for r in res], "stage_entered": t1,
+            "n_second": [r[4] for r in res], "sha_second": [r[5] for r in res], "stage_entered_second": t2,
+            "windows_second": w2}
+
+
+def sec_config5_grouped(pool):
+    spec = FULLSIZE["config5_grouped"]
+    res = sorted(pool.map(w_chain_grouped, [(spec, f) for f in range(spec["frames"])], chunksize=1))
+    return {**spec, "n_raw": [r[1] for r in res], "n_faces": [r[2] for r in res], "sha_faces": [r[3] for r in res],
+            "n_second": [r[4] for r in res], "sha_second": [r[5] for r in res]}
+
+
+def sec_opencv(pool):
+    return pool.map(w_opencv, FULLSIZE["opencv"], chunksize=1)
+
+
+def sec_modes(pool):
+    return pool.map(w_mode, FULLSIZE["modes"], chunksize=1)
+
+
+SECTIONS = {"config3": sec_config3, "modes": sec_modes, "config4": sec_config4, "config5_raw": sec_config5_raw,
+            "config5_grouped": sec_config5_grouped, "opencv": sec_opencv}
+
+if __name__ == "__main__":
+    want = sys.argv[1:] or list(SECTIONS)
+    out = json.load(open(OUT)) if os.path.exists(OUT) else {}
+    with Pool(int(os.environ.get("VJ_JOBS", "8"))) as pool:
+        for name in want:
+            t = time.time()
+            out[name] = SECTIONS[name](pool)
+            print(f"{name}: {time.time() - t:.0f} s", flush=True)
+            json.dump(out, open(OUT, "w"), separators=(",", ":"))
+    print("wrote", OUT, os.path.getsize(OUT), "bytes")
