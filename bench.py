@@ -5,8 +5,12 @@ Metric (BASELINE.json): candidate windows/sec (+ Mpix/s) on 1080p frames with
 haarcascade_frontalface_alt, 1/2/4/8 GPUs — BASELINE config 3.  A "step" is one pass of the whole hot path
 (integral + squared-integral kernels, all cascade passes, detection read-back and — for
 N > 1 — the all-gather of detection rectangles) over one batch of synthetic frames that
-is already resident in HBM.  Per-GPU work is fixed (weak scaling): every rank owns a
-batch of --frames 1080p frames; there is no data-path collective besides that gather.
+is already resident in HBM.  BASELINE config 3 is a FIXED batch of 64 frames sharded over the GPUs, so the headline
+line is strong scaling: --frames is the whole job's batch and rank r takes its vj_shard_frames block of whole
+frames (it integrates only its own frames; the only collective is the final gather of rectangles).  For N > 1 the
+same run also times the weak-scaling variant (--frames per GPU) into `weak_scaling`; `per_rank_ms_per_step` and
+`rccl_ranks` say what every rank did and how many ranks the collective really spanned.  `--scaling weak` makes
+the weak variant the headline instead.  At N = 1 the two are the same run.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -73,7 +77,11 @@ def main() -> int:
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="1080p frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=64,
+                    help="1080p frames per step: of the whole job (strong scaling) or per GPU (weak)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong: --frames frames in total, sharded by whole frames (BASELINE config 3 as stated); "
+                         "weak: --frames frames per GPU")
     ap.add_argument("--width", type=int, default=1920)
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cascade", default="frontalface_alt")
@@ -123,90 +131,111 @@ def main() -> int:
     if args.blocks_per_cu is not None:
         env.configure("blocks_per_cu", args.blocks_per_cu)
     casc = Cascade.load(args.cascade)
-    H, W, B = args.height, args.width, args.frames
-
-    # synthetic frames (seeds 1.., kinds cycling noise / smooth / blocks), per rank
-    frames_h = synth.batch(B, H, W, seed0=1 + rank * B)
-    frames_d = torch.from_numpy(frames_h).to(dev)
-    torch.cuda.synchronize()
-    dframes = DeviceFrames.from_torch(frames_d)
+    H, W = args.height, args.width
     windows_per_frame = casc.count_windows(W, H)
-
-    def step(params):
-        r = env.detect(casc, dframes, params)
-        rects = r.rects
-        if world > 1:
-            rects = rects.copy()
-            rects["frame"] += rank * B          # global frame index
-            rects = multigpu.allgather_rects(rects, device=coll_dev)
-        return r, rects
+    kinds = ("noise", "smooth", "blocks")
+    p = default_params()
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # one counted run: algorithmic bytes per launch (the counted kernel variants are slower and never timed)
-    counted, _ = step(default_params(flags=VJ_FLAG_COUNTERS))
-    p = default_params()
-    # The timed steps go through a vj_stream (two batches in flight): step k's read-back, decode and sort on the host
-    # overlap step k+1's kernels.  Every step still does everything — integral images, all cascade passes, read-back,
-    # sorted rectangles (and the all-gather for N > 1) — and all of it completes inside the timed bracket; the frames
-    # are device-resident, so the stream uses them in place (no copy).  --no-pipeline times blocking calls instead.
-    stream = None if args.no_pipeline else env.stream(casc, W, H, B, p)
+    def measure(scaling):
+        """One scaling variant: this rank's frames on the device, a counted run, warm-up, args.steps timed steps."""
+        if scaling == "strong":
+            mine = multigpu.shard_frames(args.frames, rank, world)      # == vj_shard_frames: contiguous blocks of whole frames
+            first, B, job_frames = mine.start, len(mine), args.frames
+        else:
+            first, B, job_frames = rank * args.frames, args.frames, args.frames * world
+        # global frame g has seed 1 + g and kind g % 3 whatever the number of ranks: the job's result does not depend on N
+        frames_h = np.empty((max(B, 1), H, W), np.uint8)
+        for i in range(max(B, 1)):
+            frames_h[i] = synth.frame(kinds[(first + i) % 3], 1 + first + i, H, W)
+        frames_d = torch.from_numpy(frames_h).to(dev)
+        torch.cuda.synchronize()
+        dframes = DeviceFrames.from_torch(frames_d[:B]) if B > 0 else None
 
-    def finish(r):
-        rects = r.rects
-        if world > 1:
-            rects = rects.copy()
-            rects["frame"] += rank * B
-            rects = multigpu.allgather_rects(rects, device=coll_dev)
-        return r, rects
+        def finish(r):
+            rects = r.rects
+            if world > 1:
+                rects = rects.copy()
+                rects["frame"] += first             # global frame index
+                rects = multigpu.allgather_rects(rects, device=coll_dev)
+            return r, rects
 
-    def run_steps(n):
-        """n whole steps; yields (result, gathered rects) of each."""
-        if stream is None:
-            for _ in range(n):
-                yield step(p)
-            return
-        if n == 0:
-            return
-        stream.submit(dframes)
-        for _ in range(n - 1):
+        def step(params):
+            return finish(env.detect(casc, dframes if B > 0 else [], params))
+
+        # one counted run: algorithmic bytes per launch (the counted kernel variants are slower and never timed)
+        counted, _ = step(default_params(flags=VJ_FLAG_COUNTERS))
+        # The timed steps go through a vj_stream (two batches in flight): step k's read-back, decode and sort on the host
+        # overlap step k+1's kernels.  Every step still does everything — integral images, all cascade passes, read-back,
+        # sorted rectangles (and the all-gather for N > 1) — and all of it completes inside the timed bracket; the frames
+        # are device-resident, so the stream uses them in place (no copy).  --no-pipeline times blocking calls instead.
+        stream = None if (args.no_pipeline or B == 0) else env.stream(casc, W, H, B, p)
+
+        def run_steps(n):
+            """n whole steps; yields (result, gathered rects) of each."""
+            if stream is None:
+                for _ in range(n):
+                    yield step(p)
+                return
+            if n == 0:
+                return
             stream.submit(dframes)
+            for _ in range(n - 1):
+                stream.submit(dframes)
+                yield finish(stream.collect())
             yield finish(stream.collect())
-        yield finish(stream.collect())
 
-    for _ in run_steps(args.warmup):
-        pass
-    barrier()
-    t0 = time.perf_counter()
-    integral_ms = cascade_ms = 0.0
-    pass_ms = None
-    launch_ms = None
-    launches = None
-    n_det_total = 0
-    timed_rects = None
-    for r, rects in run_steps(args.steps):
-        integral_ms += r.integral_ms
-        cascade_ms += r.cascade_ms
-        pm = [x[2] for x in r.passes]
-        pass_ms = pm if pass_ms is None else [a + b for a, b in zip(pass_ms, pm)]
-        lm = [l["ms"] for l in r.launches]
-        launch_ms = lm if launch_ms is None else [a + b for a, b in zip(launch_ms, lm)]
-        launches = r.launches
-        n_det_total = len(rects)
-        timed_rects = r.rects
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        for _ in run_steps(args.warmup):
+            pass
+        barrier()
+        t0 = time.perf_counter()
+        m = {"integral_ms": 0.0, "cascade_ms": 0.0, "pass_ms": None, "launch_ms": None, "launches": None,
+             "n_det_total": 0, "timed_rects": None}
+        for r, rects in run_steps(args.steps):
+            m["integral_ms"] += r.integral_ms
+            m["cascade_ms"] += r.cascade_ms
+            pm = [x[2] for x in r.passes]
+            m["pass_ms"] = pm if m["pass_ms"] is None else [a + b for a, b in zip(m["pass_ms"], pm)]
+            lm = [l["ms"] for l in r.launches]
+            m["launch_ms"] = lm if m["launch_ms"] is None else [a + b for a, b in zip(m["launch_ms"], lm)]
+            m["launches"] = r.launches
+            m["n_det_total"] = len(rects)
+            m["timed_rects"] = r.rects
+        own = time.perf_counter() - t0        # this rank's own steps (before it waits for the others)
+        barrier()
+        elapsed = time.perf_counter() - t0
+        per_rank = [own]
+        if world > 1:
+            t = torch.tensor([elapsed], dtype=torch.float64, device=coll_dev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+            mine_t = torch.tensor([own], dtype=torch.float64, device=coll_dev)
+            alls = [torch.zeros_like(mine_t) for _ in range(world)]
+            dist.all_gather(alls, mine_t)
+            per_rank = [float(x.item()) for x in alls]
+        if stream is not None:
+            stream.close()
+        K = max(args.steps, 1)
+        m.update(scaling=scaling, first=first, B=B, job_frames=job_frames, frames_h=frames_h, dframes=dframes, counted=counted,
+                 elapsed=elapsed, ms_per_step=1e3 * elapsed / K, per_rank_ms=[round(1e3 * x / K, 4) for x in per_rank],
+                 value=windows_per_frame * job_frames * args.steps / elapsed, keep=frames_d)
+        return m
 
-    total_windows = windows_per_frame * B * world * args.steps
-    value = total_windows / elapsed
-    ms_per_step = 1e3 * elapsed / max(args.steps, 1)
+    m = measure(args.scaling)
+    other = None
+    if world > 1:      # the other variant in the same run, so that both figures come from the same box and build
+        o = measure("weak" if args.scaling == "strong" else "strong")
+        other = {"scaling": o["scaling"], "value": round(o["value"], 1), "unit": "windows/s", "ms_per_step": round(o["ms_per_step"], 4),
+                 "frames_per_step_whole_job": o["job_frames"], "per_rank_ms_per_step": o["per_rank_ms"]}
+        del o
+    elapsed, ms_per_step, value = m["elapsed"], m["ms_per_step"], m["value"]
+    B, frames_h, dframes, counted = m["B"], m["frames_h"], m["dframes"], m["counted"]
+    integral_ms, cascade_ms, pass_ms, launch_ms, launches = m["integral_ms"], m["cascade_ms"], m["pass_ms"], m["launch_ms"], m["launches"]
+    n_det_total, timed_rects = m["n_det_total"], m["timed_rects"]
 
     out = None
     if rank == 0:
@@ -341,15 +370,23 @@ def main() -> int:
         out = {
             "metric": "candidate windows/sec, 1080p, haarcascade_frontalface_alt",
             "value": round(value, 1), "unit": "windows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": m["scaling"], "vs_baseline": None,
             "dtype": "u32 gathers + f32 stage sums", "data": "synthetic",
-            "config": {"workload": f"BASELINE config 3: {B}x{W}x{H} 8-bit frames per GPU per step (noise/smooth/blocks mix), "
-                                   f"haarcascade_{args.cascade}, scaleFactor 1.1f, raw candidates, frames resident in HBM",
-                       "frames_per_gpu": B, "windows_per_frame": windows_per_frame,
+            "config": {"workload": f"BASELINE config 3: {m['job_frames']}x{W}x{H} 8-bit frames per step in the whole job "
+                                   f"(noise/smooth/blocks mix; {'sharded by whole frames over' if m['scaling'] == 'strong' else 'per-GPU batches of ' + str(B) + ' on'} "
+                                   f"{world} GPU{'s' if world > 1 else ''}), haarcascade_{args.cascade}, scaleFactor 1.1f, raw candidates, "
+                                   f"frames resident in HBM",
+                       "frames_per_step_whole_job": m["job_frames"], "frames_on_rank_0": B, "windows_per_frame": windows_per_frame,
+                       "parallelism": f"frames sharded over {world} rank{'s' if world > 1 else ''} (vj_shard_frames), "
+                                      "no data-path collective, one all-gather of rectangles" if world > 1 else "single GPU",
                        "pass_split": [x[0] for x in counted.passes], "device": env.device_name,
                        "pipeline": "blocking vj_detect calls" if args.no_pipeline else "vj_stream, two batches in flight"},
-            "mpix_per_s": round(W * H * B * world * args.steps / elapsed / 1e6, 1),
-            "frames_per_s": round(B * world * args.steps / elapsed, 1),
+            "mpix_per_s": round(W * H * m["job_frames"] * args.steps / elapsed / 1e6, 1),
+            "frames_per_s": round(m["job_frames"] * args.steps / elapsed, 1),
+            "per_rank_ms_per_step": m["per_rank_ms"],
+            "rccl_ranks": (dist.get_world_size() if args.backend == "nccl" else 0) if world > 1 else 1,
+            "collective_backend": (args.backend if world > 1 else None),
+            ("weak_scaling" if m["scaling"] == "strong" else "strong_scaling"): other,
             "detections_last_step": int(n_det_total),
             "kernel_ms_per_step": {"integral": round(integral_ms / K, 4), "cascade": round(cascade_ms / K, 4),
                                    "cascade_passes": [round(x / K, 4) for x in pass_ms],
@@ -361,8 +398,6 @@ def main() -> int:
             "roofline": roofline, "kernels": per_kernel, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_mt,
             "cpu_baseline_opencvlike": cpu_cv, "opencv_profile": cv_profile, "parity_sample_ok": parity, "extra": extra,
         }
-    if stream is not None:
-        stream.close()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
