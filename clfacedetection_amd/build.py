@@ -16,11 +16,12 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libvjhip.so")
 SOURCES = ["vj_cascade.cpp", "vj_plan.cpp", "vj_group.cpp", "vj_env.cpp", "vj_cv.cpp", "vj_kernels.hip",
-           "vj_cv_profile.hip", "vj_group_dev.hip"]
+           "vj_cv_profile.hip", "vj_cv_tile.hip", "vj_group_dev.hip"]
 HEADERS = ["vj_internal.hpp", "vj_device.hpp", "vj_env_internal.hpp", "vj_devutil.hpp", os.path.join("..", "..", "include", "vj.h")]
 FLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", "--offload-arch=gfx950",
          "-Wall", "-Wno-unused-function", "-fvisibility=hidden", "-DVJ_BUILDING"] + \
-    (["-DVJ_STAMPS=1"] if os.environ.get("VJ_STAMPS") else [])
+    (["-DVJ_STAMPS=1"] if os.environ.get("VJ_STAMPS") else []) + \
+    [f"-D{k}={v}" for k, v in (kv.split("=", 1) for kv in os.environ.get("VJ_DEFINES", "").split(",") if "=" in kv)]   # experiment switches
 
 
 def _hipcc() -> str:

@@ -88,7 +88,9 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
     std::vector<CvScaleDev>& scales = pl->scales;
     scales.assign(hs.size(), CvScaleDev{});
     std::vector<CvNodeRec> table(hs.size() * n_nodes);
+    table.reserve(2 * hs.size() * n_nodes);   // tile copies of the small scales' records are appended: no reallocation, `recs` stays valid
     std::vector<UnitDev> rows;
+    std::vector<int> tile_class(hs.size(), -1);
     bool reach_ok = true;
     const uint32_t frame_elems = frame_elems_for(W, H);
     for (size_t k = 0; k < hs.size(); ++k) {
@@ -178,6 +180,93 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
         const uint64_t origin_max = (uint64_t)(H - hs[k].win_h) * stride + (uint64_t)(W - hs[k].win_w);
         if (origin_max + max_reach >= (uint64_t)frame_elems) reach_ok = false;
         for (uint32_t iy = 0; iy < sd.end_y; ++iy) rows.push_back(UnitDev{(uint32_t)k, iy, 0, 0});
+
+        // ---- LDS-tile path (vj_cv_tile.hip): stump cascades with linear stages and upright features.  A tile is tw x th
+        // windows (tw divides 64, so a tile row never straddles a word of the reject / visited bitmap); its footprint is
+        // the span of its window origins plus the furthest corner any feature or the equRect reaches.  Two LDS classes
+        // like the clod profile's tiles: two workgroups per CU or one, next to one workgroup of cv_profile_pass.
+        if (e->cv_tiles && !trees && !is_tree && !has_tilted && sd.end_x < 65536u && sd.end_y < 65536u) {
+            uint32_t reach_x = (uint32_t)(ex + ew), reach_y = (uint32_t)(ex + eh);
+            for (size_t n = 0; n < n_nodes; ++n) {
+                const CvNodeRec& r = recs[n];
+                for (int q = 0; q < 3; ++q)
+                    if (q < 2 || r.w[2] != 0.0f) {
+                        const uint32_t p0 = r.lt[q] / 4u;
+                        reach_x = std::max(reach_x, p0 % stride + r.da[q] / 4u);
+                        reach_y = std::max(reach_y, p0 / stride + (r.db[q] / 4u) / stride);
+                    }
+            }
+            static const uint32_t kTw[] = {64, 32, 16}, kTh[] = {32, 24, 16, 12, 8, 4};
+            const uint32_t class_bytes[2] = {45u * 1024u, 112u * 1024u};
+            uint32_t best_n = 0, b_tw = 0, b_th = 0, b_pitch = 0, b_rows = 0;
+            int b_cls = -1;
+            for (int cls = 0; cls < 2 && b_cls < 0; ++cls) {
+                for (uint32_t tw : kTw)
+                    for (uint32_t th : kTh) {
+                        const uint32_t pitch = (((uint32_t)std::ceil((double)(tw - 1) * sd.ystep) + 3u + reach_x) + 3u) & ~3u;
+                        const uint32_t trows = (uint32_t)std::ceil((double)(th - 1) * sd.ystep) + 3u + reach_y;
+                        if ((uint64_t)pitch * trows * 4u > class_bytes[cls]) continue;
+                        const uint32_t nwin = std::min(tw, sd.end_x) * std::min(th, sd.end_y);
+                        if (nwin > best_n) { best_n = nwin; b_tw = tw; b_th = th; b_pitch = pitch; b_rows = trows; }
+                    }
+                // a class-0 tile must be worth two workgroups per CU; else try the larger class
+                if (best_n >= (uint32_t)e->cv_tile_min_windows * (cls == 0 ? 2u : 1u))
+                    b_cls = cls;
+                else
+                    best_n = 0;
+            }
+            if (b_cls >= 0) {
+                sd.tile_tw = b_tw;
+                sd.tile_th = b_th;
+                sd.tile_pitch = b_pitch;
+                sd.tile_rows = b_rows;
+                sd.tile_table_first = (uint32_t)table.size();
+                tile_class[k] = b_cls;
+                table.resize(table.size() + n_nodes);   // (within the reserved capacity)
+                CvNodeRec* trec = table.data() + sd.tile_table_first;
+                for (size_t n = 0; n < n_nodes; ++n) {
+                    trec[n] = recs[n];
+                    for (int q = 0; q < 3; ++q)
+                        if (q < 2 || recs[n].w[2] != 0.0f) {
+                            const uint32_t p0 = recs[n].lt[q] / 4u, hh = (recs[n].db[q] / 4u) / stride;
+                            trec[n].lt[q] = ((p0 / stride) * b_pitch + p0 % stride) * 4u;
+                            trec[n].db[q] = hh * b_pitch * 4u;
+                        }
+                }
+            }
+        }
+    }
+    // tiles of one frame by LDS class; rows of the scales that stay on cv_profile_pass; one recurrence domain per window
+    // row of a tile scale in the per-frame bitmap
+    std::vector<UnitDev> tiles, rows_rest, bit_segs;
+    pl->n_tile_scales = 0;
+    {
+        uint32_t word = 0;
+        for (size_t k = 0; k < hs.size(); ++k) {
+            CvScaleDev& sd = scales[k];
+            if (sd.tile_th == 0u) continue;
+            ++pl->n_tile_scales;
+            sd.bits_base = word;
+            const uint32_t wpr = (sd.end_x + 63u) / 64u;
+            for (uint32_t iy = 0; iy < sd.end_y; ++iy) bit_segs.push_back(UnitDev{(uint32_t)k, word + iy * wpr, wpr, 0});
+            word += wpr * sd.end_y;
+        }
+        pl->bits_frame_words = word;
+        for (int cls = 0; cls < 2; ++cls) {
+            pl->class_first[cls] = (uint32_t)tiles.size();
+            uint32_t lds = 0;
+            for (size_t k = 0; k < hs.size(); ++k) {
+                const CvScaleDev& sd = scales[k];
+                if (sd.tile_th == 0u || tile_class[k] != cls) continue;
+                lds = std::max(lds, (uint32_t)CVT_LDS_HEADER + sd.tile_pitch * sd.tile_rows * 4u);
+                for (uint32_t iy0 = 0; iy0 < sd.end_y; iy0 += sd.tile_th)
+                    for (uint32_t ix0 = 0; ix0 < sd.end_x; ix0 += sd.tile_tw) tiles.push_back(UnitDev{(uint32_t)k, ix0 | (iy0 << 16), 0, 0});
+            }
+            pl->class_lds[cls] = lds;
+        }
+        pl->class_first[2] = (uint32_t)tiles.size();
+        for (const UnitDev& r : rows)
+            if (scales[r.scale].tile_th == 0u) rows_rest.push_back(r);
     }
     std::vector<StageDev> stages(c->stages.size());
     for (size_t s = 0; s < c->stages.size(); ++s) {
@@ -191,6 +280,16 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
         stages[s].order = s < order.size() ? order[s] : 0u;
         // an f64 product per rectangle only on cvRunHaarClassifierCascadeSum's stump path (:863-888)
         stages[s].cv_f64 = (two_rects[s] && !trees && !is_tree) ? 1u : 0u;
+        // wave-split finish of the tile kernel: bound on the difference between any two summation orders of the stage's
+        // leaf values (the f32 form of the clod profile's bound, build_plan; the kernel scales it to f64's unit roundoff)
+        double amax = 0.0;
+        for (int t = 0; t < c->stages[s].n_trees; ++t) {
+            const vj_tree_desc& td = c->trees[c->stages[s].first_tree + t];
+            double m = 0.0;
+            for (int k = 0; k <= td.n_nodes; ++k) m = std::max(m, (double)std::fabs(c->alpha[td.first_alpha + k]));
+            amax += m;
+        }
+        stages[s].sp_delta = (float)(4.0 * (double)prog.n_nodes[s] * std::ldexp(1.0, -24) * amax * 1.001 + 1e-30);
     }
     if (!reach_ok) {
         set_error("feature reach exceeds the frame allocation");
@@ -202,6 +301,14 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
     if ((rc = pl->d_scales.ensure(std::max<size_t>(scales.size(), 1) * sizeof(CvScaleDev)))) return rc;
     if ((rc = pl->d_stages.ensure(stages.size() * sizeof(StageDev)))) return rc;
     if ((rc = pl->d_rows.ensure(std::max<size_t>(rows.size(), 1) * sizeof(UnitDev)))) return rc;
+    if ((rc = pl->d_tiles.ensure(std::max<size_t>(tiles.size(), 1) * sizeof(UnitDev)))) return rc;
+    if ((rc = pl->d_rows_rest.ensure(std::max<size_t>(rows_rest.size(), 1) * sizeof(UnitDev)))) return rc;
+    if ((rc = pl->d_bit_segs.ensure(std::max<size_t>(bit_segs.size(), 1) * sizeof(UnitDev)))) return rc;
+    if (!tiles.empty()) HIP_TRY(hipMemcpy(pl->d_tiles.p, tiles.data(), tiles.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
+    if (!rows_rest.empty()) HIP_TRY(hipMemcpy(pl->d_rows_rest.p, rows_rest.data(), rows_rest.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
+    if (!bit_segs.empty()) HIP_TRY(hipMemcpy(pl->d_bit_segs.p, bit_segs.data(), bit_segs.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
+    pl->n_rows_rest = (uint32_t)rows_rest.size();
+    pl->n_bit_segs = (uint32_t)bit_segs.size();
     if (!table.empty()) HIP_TRY(hipMemcpy(pl->d_table.p, table.data(), table.size() * sizeof(CvNodeRec), hipMemcpyHostToDevice));
     if (!scales.empty()) HIP_TRY(hipMemcpy(pl->d_scales.p, scales.data(), scales.size() * sizeof(CvScaleDev), hipMemcpyHostToDevice));
     HIP_TRY(hipMemcpy(pl->d_stages.p, stages.data(), stages.size() * sizeof(StageDev), hipMemcpyHostToDevice));
@@ -285,7 +392,8 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
     const uint32_t frame_elems = frame_elems_for(W, H);
     DevBuf& d_det = e->d_cv_det;
     DevBuf& d_counts = e->d_cv_counts;
-    const size_t counts_bytes = 2 * VJ_MAX_STAGES * sizeof(uint64_t) + 16;
+    // counters: stage_entered[VJ_MAX_STAGES] | visited | ... | detection count | pad | 4 x 8 tile ticket counters
+    const size_t counts_bytes = 2 * VJ_MAX_STAGES * sizeof(uint64_t) + 16 + 4 * 8 * sizeof(uint32_t);
     if ((rc = d_counts.ensure(counts_bytes))) return rc;
 
     const bool count = (p->flags & VJ_FLAG_COUNTERS) != 0;
@@ -324,22 +432,96 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             a.frame_elems = frame_elems;
             a.stride = stride;
             a.sum_h = (uint32_t)H + 1u;
-            // four workgroups (16 waves) per CU: every wave walks its own window row, and the rows in flight on an XCD
-            // should stay inside its 4 MiB L2 (64 x 1080p: 376 / 235 / 179 / 153 / 173 / 194 / 193 ms for 1 / 2 / 3 / 4 / 5 / 6 / 8)
-            const int n_blocks = std::max(1, e->n_cu * 4);
-            a.total_waves = (uint32_t)n_blocks * CV_WAVES_PER_BLOCK;
             a.det = (CvDet*)d_det.p;
             a.det_count = (uint32_t*)((unsigned long long*)d_counts.p + 2 * VJ_MAX_STAGES);
             a.det_cap = det_cap;
             a.stage_entered = (unsigned long long*)d_counts.p;
             HIP_TRY(hipEventRecord(e->lane0.ev[2], e->stream));
-            const int hrc = launch_cv_profile_pass(a, trees, count, is_tree, n_blocks, e->stream);
+            int hrc = 0;
+            const bool tiles = pl->n_tile_scales != 0 && pl->class_first[2] != 0;
+            if (tiles) {
+                // The small scales on LDS tiles (vj_cv_tile.hip), the rest on cv_profile_pass, concurrently on two streams:
+                // the row kernel is bound by the texture-address unit, the tile kernel by LDS and VALU.  The row kernel is
+                // launched first with one workgroup per CU so that the tile workgroups find their LDS share next to it.
+                if ((rc = e->d_skip_bits.ensure((size_t)pl->bits_frame_words * 8u * (size_t)nf))) return rc;
+                HIP_TRY(hipMemsetAsync(e->d_skip_bits.p, 0, (size_t)pl->bits_frame_words * 8u * (size_t)nf, e->stream));
+                const bool two = e->concurrent && pl->n_rows_rest != 0;
+                hipStream_t sB = two ? e->stream2 : e->stream;
+                if (two) {
+                    HIP_TRY(hipEventRecord(e->fork_ev, e->stream));
+                    HIP_TRY(hipStreamWaitEvent(e->stream2, e->fork_ev, 0));
+                }
+                if (pl->n_rows_rest != 0) {
+                    CvArgs b = a;
+                    b.rows = (const UnitDev*)pl->d_rows_rest.p;
+                    b.n_rows = pl->n_rows_rest;
+                    const int nb = std::max(1, e->n_cu * (two ? 1 : 4));
+                    b.total_waves = (uint32_t)nb * CV_WAVES_PER_BLOCK;
+                    hrc = launch_cv_profile_pass(b, trees, count, is_tree, nb, sB);
+                }
+                CvTileArgs t;
+                memset(&t, 0, sizeof(t));
+                t.sum = a.sum;
+                t.sqsum = a.sqsum;
+                t.table = a.table;
+                t.scales = a.scales;
+                t.stages = a.stages;
+                t.n_frames = (uint32_t)nf;
+                t.n_stages = pl->n_stages;
+                t.frame_elems = frame_elems;
+                t.stride = stride;
+                t.sum_h = a.sum_h;
+                t.bits = (unsigned long long*)e->d_skip_bits.p;
+                t.bits_frame_words = pl->bits_frame_words;
+                t.repack_mask = ~3ull;        // before every stage from 2 on (as the clod profile's tiles)
+                t.ws_begin = 3;
+                t.ws_max = (uint32_t)e->cv_tile_ws_max;
+                t.det = a.det;
+                t.det_count = a.det_count;
+                t.det_cap = det_cap;
+                t.stage_entered = a.stage_entered;
+                uint32_t* tickets = a.det_count + 4;
+                for (int mode = 0; mode < 2 && !hrc; ++mode) {
+                    for (int cls = 0; cls < 2 && !hrc; ++cls) {
+                        const uint32_t n_cls = pl->class_first[cls + 1] - pl->class_first[cls];
+                        if (!n_cls) continue;
+                        CvTileArgs ta = t;
+                        ta.tiles = (const UnitDev*)pl->d_tiles.p + pl->class_first[cls];
+                        ta.n_tiles = n_cls;
+                        ta.lds_bytes = pl->class_lds[cls];
+                        ta.ticket = tickets + 8 * (mode * 2 + cls);
+                        const int per_cu = std::max(1, std::min(2, (int)((160u * 1024u - 20u * 1024u) / ta.lds_bytes)));
+                        const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
+                        hrc = launch_cv_tile_pass(ta, mode, count, std::max(1, tb), e->stream);
+                    }
+                    if (mode == 0 && !hrc) {   // reject bits -> visited bits, one recurrence domain per window row (skip_resolve)
+                        CascadeArgs ra;
+                        memset(&ra, 0, sizeof(ra));
+                        ra.skip_bits = (unsigned long long*)e->d_skip_bits.p;
+                        ra.skip_frame_words = pl->bits_frame_words;
+                        ra.skip_segs = (const UnitDev*)pl->d_bit_segs.p;
+                        ra.n_skip_segs = pl->n_bit_segs;
+                        ra.n_frames = (uint32_t)nf;
+                        hrc = launch_skip_resolve(ra, std::max(1, e->n_cu * 2), e->stream);
+                    }
+                }
+                if (two) {
+                    HIP_TRY(hipEventRecord(e->join_ev, e->stream2));
+                    HIP_TRY(hipStreamWaitEvent(e->stream, e->join_ev, 0));
+                }
+            } else {
+                // four workgroups (16 waves) per CU: every wave walks its own window row, and the rows in flight on an XCD
+                // should stay inside its 4 MiB L2 (64 x 1080p: 376 / 235 / 179 / 153 / 173 / 194 / 193 ms for 1 / 2 / 3 / 4 / 5 / 6 / 8)
+                const int n_blocks = std::max(1, e->n_cu * 4);
+                a.total_waves = (uint32_t)n_blocks * CV_WAVES_PER_BLOCK;
+                hrc = launch_cv_profile_pass(a, trees, count, is_tree, n_blocks, e->stream);
+            }
             if (hrc) {
                 set_error("cascade launch failed: %s", hipGetErrorString((hipError_t)hrc));
                 return VJ_ERR_HIP;
             }
             HIP_TRY(hipEventRecord(e->lane0.ev[3], e->stream));
-            std::vector<unsigned long long> h(2 * VJ_MAX_STAGES + 2);
+            std::vector<unsigned long long> h((counts_bytes + 7) / 8);
             HIP_TRY(hipMemcpyAsync(h.data(), d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));
             const uint32_t n_det = (uint32_t)(h[2 * VJ_MAX_STAGES] & 0xffffffffull);

@@ -301,7 +301,12 @@ struct CvScaleDev {
     uint32_t q0, q1, q2, q3;   // the four corners of equRect, element offsets from the window origin
     uint32_t table_first;  // first NodeRec of this scale
     uint32_t scale_idx;    // index of the factor in the enumeration (skipped scales keep their number)
-    uint32_t pad[6];
+    // LDS-tile path of the profile (vj_cv_tile.hip; tile_th == 0: the scale runs on cv_profile_pass)
+    uint32_t tile_tw, tile_th;   // windows per tile row (64, 32 or 16: a tile row never straddles a bitmap word) and rows per tile (<= 32)
+    uint32_t tile_pitch;         // dwords per row of the LDS image tile (a multiple of 4)
+    uint32_t tile_rows;          // rows of the LDS image tile
+    uint32_t tile_table_first;   // first CvNodeRec of this scale built with the tile's pitch
+    uint32_t bits_base;          // first word of this scale in a frame's reject / visited bitmap ((end_x + 63) / 64 words per window row)
 };
 static_assert(sizeof(CvScaleDev) == 80, "CvScaleDev is 80 bytes");
 
@@ -350,6 +355,38 @@ struct CvArgs {
 };
 
 int launch_cv_profile_pass(const CvArgs& a, bool trees, bool count, bool stage_tree, int n_blocks, void* stream);
+
+// The profile's LDS-tile kernel (vj_cv_tile.hip): small scales of stump cascades with linear stages and upright features.
+constexpr int CVT_WAVES = 8;            // waves per workgroup
+constexpr int CVT_WAVE_CAP = 256;       // windows (queue entries) per wave: four tile rows of <= 64 windows
+constexpr int CVT_WS_MAX = 512;         // windows a tile may carry into the wave-split finish
+constexpr int CVT_LDS_HEADER = CVT_WAVES * CVT_WAVE_CAP * 12 + 256;   // offset queue (u32) + norm-factor queue (f64) + counters, bytes
+struct CvTileArgs {
+    const uint32_t* sum;
+    const uint64_t* sqsum;
+    const uint32_t* table;       // CvNodeRec[] (the tile scales' records carry offsets in the tile's pitch)
+    const CvScaleDev* scales;
+    const StageDev* stages;      // as CvArgs::stages, plus sp_delta (order-independence bound of a stage's leaf sum)
+    const UnitDev* tiles;        // tiles of ONE frame in this launch's LDS class: {scale slot, ix0 | iy0 << 16}
+    uint32_t n_tiles;
+    uint32_t* ticket;            // eight ticket counters of this launch (zeroed before it)
+    uint32_t n_frames, n_stages, frame_elems;
+    uint32_t stride;             // W + 1
+    uint32_t sum_h;              // H + 1
+    unsigned long long* bits;    // [n_frames][bits_frame_words]: stage-0 reject bits (pass 0), visited bits after skip_resolve
+    uint32_t bits_frame_words;
+    uint32_t lds_bytes;          // dynamic LDS of the launch
+    unsigned long long repack_mask;   // bit s: pool the tile's survivors across its waves before stage s
+    uint32_t ws_begin, ws_max;   // wave-split finish from this stage on, once at most ws_max (<= CVT_WS_MAX) windows are left
+    CvDet* det;
+    uint32_t* det_count;
+    uint32_t det_cap;
+    unsigned long long* stage_entered;   // as CvArgs
+};
+int launch_cv_tile_pass(const CvTileArgs& a, int mode /* 0: reject bits of stage 0, 1: the cascade on the visited windows */, bool count,
+                        int n_blocks, void* stream);
+int prepare_cv_tile_kernels();   // per device: raise the dynamic-LDS cap
+int launch_skip_resolve(const CascadeArgs& a, int n_blocks, void* stream);   // reject bits -> visited bits (vj_kernels.hip)
 
 struct TiltedArgs {
     const uint8_t* gray;        // batch of frames

@@ -1569,6 +1569,10 @@ int vj_env_create(int device_index, vj_env** out) {
         set_error("raising the dynamic LDS limit on device %d failed: %s", device_index, hipGetErrorString((hipError_t)hrc));
         return VJ_ERR_HIP;
     }
+    if (const int hrc = prepare_cv_tile_kernels()) {
+        set_error("raising the dynamic LDS limit on device %d failed: %s", device_index, hipGetErrorString((hipError_t)hrc));
+        return VJ_ERR_HIP;
+    }
     if (const int hrc = prepare_group_kernels()) {
         set_error("raising the dynamic LDS limit on device %d failed: %s", device_index, hipGetErrorString((hipError_t)hrc));
         return VJ_ERR_HIP;
@@ -1705,6 +1709,17 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "rois_on_device") == 0) {
         e->rois_on_device = atoi(value) != 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "cv_tiles") == 0 || strcmp(key, "cv_tile_ws_max") == 0 || strcmp(key, "cv_tile_min_windows") == 0) {
+        // OpenCV profile: 0 = every scale on cv_profile_pass; the finish threshold; the smallest tile worth staging
+        const int v = atoi(value);
+        if (strcmp(key, "cv_tiles") == 0) e->cv_tiles = v != 0;
+        else if (strcmp(key, "cv_tile_ws_max") == 0) e->cv_tile_ws_max = std::max(0, std::min(v, (int)CVT_WS_MAX));
+        else e->cv_tile_min_windows = std::max(64, v);
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        for (auto& kv : e->cv_plans) kv.second->release_device();
+        e->cv_plans.clear();
         return VJ_OK;
     }
     if (strcmp(key, "wide_tail") == 0) {

@@ -103,9 +103,14 @@ struct CvPlan {
     uint32_t n_stages = 0, n_order = 0, n_rows = 0;
     bool trees = false, is_tree = false, has_tilted = false;
     DevBuf d_table, d_scales, d_stages, d_rows;
+    // LDS-tile path (vj_cv_tile.hip): tiles of one frame per LDS class, the rows of the scales that stay on
+    // cv_profile_pass, and the per-frame reject / visited bitmap with one recurrence domain per window row
+    uint32_t n_tile_scales = 0, n_rows_rest = 0, bits_frame_words = 0, n_bit_segs = 0;
+    uint32_t class_first[3] = {0, 0, 0}, class_lds[2] = {0, 0};
+    DevBuf d_tiles, d_rows_rest, d_bit_segs;
     uint64_t last_used = 0;
     void release_device() {
-        for (DevBuf* b : {&d_table, &d_scales, &d_stages, &d_rows}) b->release();
+        for (DevBuf* b : {&d_table, &d_scales, &d_stages, &d_rows, &d_tiles, &d_rows_rest, &d_bit_segs}) b->release();
     }
 };
 
@@ -223,6 +228,9 @@ struct vj_env {
     int tile_deinterleave = 1;    // de-interleave the LDS tile rows of the step-2 scales
     int group_max = (int)vj::GROUP_MAX;   // vj_detect_chain groups up to this many raw candidates of one frame on the device (more: host path)
     bool tree_split_queues = true; // stage trees: the grid pass's survivors go down the tree while the tiles still run
+    bool cv_tiles = true;         // OpenCV profile: small scales of stump cascades on LDS tiles (vj_cv_tile.hip)
+    int cv_tile_ws_max = 512;     // ... windows a tile carries into its wave-split finish
+    int cv_tile_min_windows = 512;   // ... a scale goes to tiles when a tile of at least this many windows fits the LDS
     bool rois_on_device = true;   // vj_detect_rois: one region pass on the frames' integral images (0: one vj_detect per region size)
     int wide_tail = -1;           // queue passes: several windows in flight in the stump-parallel tail (-1: batches of <= 4 frames)
     int min_chunk = 32;           // queue passes: smallest chunk of windows a wave draws when there are fewer than 64 per wave

@@ -1170,6 +1170,11 @@ __global__ __launch_bounds__(256) void skip_resolve(CascadeArgs a) {
     }
 }
 
+int launch_skip_resolve(const CascadeArgs& a, int n_blocks, void* stream_) {
+    hipLaunchKernelGGL(skip_resolve, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
+
 int launch_skip_bitmap(const CascadeArgs& a, bool trees, int n_blocks, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (trees) hipLaunchKernelGGL(skip_fail_bits<true>, dim3(n_blocks), dim3(256), 0, stream, a);

@@ -201,3 +201,42 @@ def test_plan_cache_of_the_profile(env, oracle, cascades):
     finally:
         env.configure("plan_cache_max", 48)
 
+
+
+@pytest.mark.parametrize("casc,kind,seed,h,w,batch", [
+    ("frontalface_alt", "noise", 31, 300, 420, 1),
+    ("frontalface_alt", "faces", 32, 540, 960, 3),            # tiles of both LDS classes, detections inside the finish
+    ("frontalface_alt", "smooth", 33, 720, 1280, 2),          # crowded tiles: many windows pass the early stages
+    ("frontalface_default", "blocks", 34, 480, 640, 2),       # 24 x 24 window, 25 stages
+    ("eye", "noise", 35, 200, 333, 4),                        # window rows that are not a multiple of the tile width
+    ("frontalface_alt", "white", 0, 200, 500, 1),             # flat: every window rejects at stage 0 (variance 0), long skip runs
+])
+def test_lds_tile_path_equals_the_row_kernel_and_the_oracle(env, oracle, cascades, casc, kind, seed, h, w, batch):
+    """The profile's small scales run on LDS tiles (vj_cv_tile.hip: reject bits of stage 0, skip_resolve, the cascade on
+    the visited windows), the large ones on cv_profile_pass; cv_tiles = 0 sends every scale through cv_profile_pass.  Both
+    give the same rectangles, visited-window counts and per-stage counts, and they are the oracle's."""
+    c, a = cascades(casc)
+    frames = np.stack([make_frame(kind, seed + i, h, w, oracle) for i in range(batch)])
+    tiled = env.detect_opencv(c, frames, flags=VJ_FLAG_COUNTERS)
+    plain_tiled = env.detect_opencv(c, frames)
+    try:
+        env.configure("cv_tiles", 0)
+        rows_only = env.detect_opencv(c, frames, flags=VJ_FLAG_COUNTERS)
+    finally:
+        env.configure("cv_tiles", 1)
+    assert np.array_equal(tiled.rects, rows_only.rects) and np.array_equal(plain_tiled.rects, tiled.rects)
+    assert tiled.windows == rows_only.windows and tiled.stage_entered == rows_only.stage_entered
+    entered = np.zeros(len(tiled.stage_entered), np.int64)
+    vis = 0
+    for f in range(batch):
+        ro, st = oracle.detect_opencvlike(a, frames[f])
+        assert sorted(rows(tiled.rects[tiled.rects["frame"] == f])) == sorted(rows(ro)), f
+        entered += np.array(st["stage_entered"], np.int64)
+        vis += st["windows"]
+    assert tiled.stage_entered == entered.tolist() and tiled.windows == vis
+    for key, val in (("cv_tile_ws_max", 64), ("cv_tile_ws_max", 0), ("cv_tile_min_windows", 64), ("concurrent", 0)):
+        try:                                                  # finish thresholds, small tiles, one stream: same result
+            env.configure(key, val)
+            assert np.array_equal(env.detect_opencv(c, frames).rects, tiled.rects), (key, val)
+        finally:
+            env.configure(key, {"cv_tile_ws_max": 512, "cv_tile_min_windows": 512, "concurrent": 1}[key])
