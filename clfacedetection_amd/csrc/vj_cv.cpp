@@ -197,7 +197,10 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
                     }
             }
             static const uint32_t kTw[] = {64, 32, 16}, kTh[] = {32, 24, 16, 12, 8, 4};
-            const uint32_t class_bytes[2] = {45u * 1024u, 112u * 1024u};
+            // LDS budget of a CU: the row kernel's workgroups (20 KiB each) stay resident next to two tile workgroups
+            // of class 0 or one of class 1; a tile workgroup also owns CVT_LDS_HEADER bytes of queues
+            const uint32_t avail = 160u * 1024u - (uint32_t)e->cv_row_blocks * 20u * 1024u - 1024u;
+            const uint32_t class_bytes[2] = {avail / 2u - (uint32_t)CVT_LDS_HEADER, avail - (uint32_t)CVT_LDS_HEADER};
             uint32_t best_n = 0, b_tw = 0, b_th = 0, b_pitch = 0, b_rows = 0;
             int b_cls = -1;
             for (int cls = 0; cls < 2 && b_cls < 0; ++cls) {
@@ -210,7 +213,7 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
                         if (nwin > best_n) { best_n = nwin; b_tw = tw; b_th = th; b_pitch = pitch; b_rows = trows; }
                     }
                 // a class-0 tile must be worth two workgroups per CU; else try the larger class
-                if (best_n >= (uint32_t)e->cv_tile_min_windows * (cls == 0 ? 2u : 1u))
+                if (best_n >= (uint32_t)(cls == 0 ? e->cv_tile_min_windows0 : e->cv_tile_min_windows))
                     b_cls = cls;
                 else
                     best_n = 0;
@@ -455,7 +458,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                     CvArgs b = a;
                     b.rows = (const UnitDev*)pl->d_rows_rest.p;
                     b.n_rows = pl->n_rows_rest;
-                    const int nb = std::max(1, e->n_cu * (two ? 1 : 4));
+                    const int nb = std::max(1, e->n_cu * (two ? e->cv_row_blocks : 4));
                     b.total_waves = (uint32_t)nb * CV_WAVES_PER_BLOCK;
                     hrc = launch_cv_profile_pass(b, trees, count, is_tree, nb, sB);
                 }
@@ -490,7 +493,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                         ta.n_tiles = n_cls;
                         ta.lds_bytes = pl->class_lds[cls];
                         ta.ticket = tickets + 8 * (mode * 2 + cls);
-                        const int per_cu = std::max(1, std::min(2, (int)((160u * 1024u - 20u * 1024u) / ta.lds_bytes)));
+                        const int per_cu = std::max(1, std::min(2, (int)((160u * 1024u - (uint32_t)e->cv_row_blocks * 20u * 1024u) / ta.lds_bytes)));
                         const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
                         hrc = launch_cv_tile_pass(ta, mode, count, std::max(1, tb), e->stream);
                     }

@@ -230,7 +230,9 @@ struct vj_env {
     bool tree_split_queues = true; // stage trees: the grid pass's survivors go down the tree while the tiles still run
     bool cv_tiles = true;         // OpenCV profile: small scales of stump cascades on LDS tiles (vj_cv_tile.hip)
     int cv_tile_ws_max = 512;     // ... windows a tile carries into its wave-split finish
-    int cv_tile_min_windows = 512;   // ... a scale goes to tiles when a tile of at least this many windows fits the LDS
+    int cv_row_blocks = 3;        // ... workgroups per CU of cv_profile_pass while it runs next to the tiles (their LDS budget shrinks with it)
+    int cv_tile_min_windows0 = 2048;   // ... the same for the class with two tile workgroups per CU
+    int cv_tile_min_windows = 1536;   // ... a scale goes to tiles when a tile of at least this many windows fits the LDS
     bool rois_on_device = true;   // vj_detect_rois: one region pass on the frames' integral images (0: one vj_detect per region size)
     int wide_tail = -1;           // queue passes: several windows in flight in the stump-parallel tail (-1: batches of <= 4 frames)
     int min_chunk = 32;           // queue passes: smallest chunk of windows a wave draws when there are fewer than 64 per wave

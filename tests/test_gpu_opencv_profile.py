@@ -234,9 +234,13 @@ def test_lds_tile_path_equals_the_row_kernel_and_the_oracle(env, oracle, cascade
         entered += np.array(st["stage_entered"], np.int64)
         vis += st["windows"]
     assert tiled.stage_entered == entered.tolist() and tiled.windows == vis
-    for key, val in (("cv_tile_ws_max", 64), ("cv_tile_ws_max", 0), ("cv_tile_min_windows", 64), ("concurrent", 0)):
-        try:                                                  # finish thresholds, small tiles, one stream: same result
-            env.configure(key, val)
-            assert np.array_equal(env.detect_opencv(c, frames).rects, tiled.rects), (key, val)
+    defaults = {"cv_tile_ws_max": 512, "cv_tile_min_windows": 1536, "cv_tile_min_windows0": 2048, "cv_row_blocks": 3, "concurrent": 1}
+    for setting in ({"cv_tile_ws_max": 64}, {"cv_tile_ws_max": 0}, {"cv_tile_min_windows": 64, "cv_tile_min_windows0": 64},
+                    {"cv_row_blocks": 1, "cv_tile_min_windows0": 512, "cv_tile_min_windows": 512}, {"concurrent": 0}):
+        try:                         # finish thresholds, small tiles of both LDS classes, other occupancies, one stream: same result
+            for key, val in setting.items():
+                env.configure(key, val)
+            assert np.array_equal(env.detect_opencv(c, frames).rects, tiled.rects), setting
         finally:
-            env.configure(key, {"cv_tile_ws_max": 512, "cv_tile_min_windows": 512, "concurrent": 1}[key])
+            for key in setting:
+                env.configure(key, defaults[key])
