@@ -99,7 +99,7 @@ class _Timing(C.Structure):
     _fields_ = [("integral_ms", C.c_float), ("cascade_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_cascade_launches", C.c_int32), ("pass_ms", C.c_float * VJ_MAX_PASSES),
                 ("pass_stage_begin", C.c_int32 * VJ_MAX_PASSES), ("pass_stage_end", C.c_int32 * VJ_MAX_PASSES),
-                ("n_launches", C.c_int32), ("launch", _Launch * VJ_MAX_LAUNCHES)]
+                ("n_launches", C.c_int32), ("launch", _Launch * VJ_MAX_LAUNCHES), ("tile_split", C.c_float)]
 
 
 class _Result(C.Structure):
@@ -328,6 +328,7 @@ class DetectResult:
     n_cascade_launches: int
     passes: list = None          # [(stage_begin, stage_end, ms)] per cascade pass
     launches: list = None        # per kernel launch: dict(kind, lds_class, stage_begin, stage_end, ms, lds_bytes, scales)
+    tile_split: float = 0.0      # the chain balance the call's plan was built for
 
     @property
     def match_count(self) -> int:
@@ -511,7 +512,7 @@ class Environment:
                                       lds_bytes=int(l.lds_bytes),
                                       scales=[k for k in range(127) if (l.scale_mask[k >> 6] >> (k & 63)) & 1],
                                       stage_entered=[int(v) for v in l.stage_entered[:cascade.info.n_stages]])
-                                 for l in list(t.launch)[:int(t.n_launches)]])
+                                 for l in list(t.launch)[:int(t.n_launches)]], float(t.tile_split))
         finally:
             lib.vj_result_free(C.byref(res))
 

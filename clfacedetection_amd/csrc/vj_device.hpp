@@ -152,6 +152,7 @@ struct CascadeArgs {
     uint32_t wide_tail;         // queue passes: the stump-parallel tail keeps several windows' gathers in flight (small batches)
     uint32_t min_chunk;         // queue passes: smallest chunk of windows a wave draws (1..64)
     uint32_t thin_pass_spread;  // queue passes with fewer chunks than waves: only the first workgroups draw tickets (even load per CU)
+    uint32_t q_slices;          // queue passes: a part's chunks are handed out in this many slices of every scale's range (frame-major order)
     QEntry*   q_out;            // survivor queue written by this pass (not the last)
     uint32_t* q_out_count;
     QEntry*   q_fail;           // stage trees: queue of the chain that takes this pass's rejects (else null)

@@ -556,8 +556,62 @@ static int small_frame_class(const vj_env* e, int W, int H, int n_frames) {
     return px <= 115200 ? 2 : px <= 460800 ? 1 : 0;
 }
 
+// The workload whose chain balance is being found (or was found) by feedback: batches of >= 8 frames through vj_detect.
+static vj_env::Balance* balance_of(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, int n_frames, bool create) {
+    if (!e->auto_balance || e->tile_split_set || !e->concurrent || n_frames < 8 || n_frames >= (1 << 20)) return nullptr;
+    const vj_env::BalanceKey key(vj_env::PlanKey(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
+                                                 p.scale_mask[1], p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64), 0u),
+                                 n_frames);
+    auto it = e->balance.find(key);
+    if (it != e->balance.end()) return &it->second;
+    if (!create) return nullptr;
+    if (e->balance.size() > 256) e->balance.clear();   // bounded
+    vj_env::Balance b;
+    b.cur = b.best = e->split_for(n_frames);
+    return &(e->balance[key] = b);
+}
+
+// One more measured call (cascade kernels' time, uncounted variants) of a workload that is still being balanced.  Three
+// calls per candidate, the first of which pays for the plan: the fastest counts.  Steps of half a scale; a move needs 0.7 %.
+static void balance_report(vj_env::Balance* b, float ms) {
+    if (!b || b->phase == 3 || !(ms > 0.0f)) return;
+    ++b->calls;
+    if (++b->samples == 1) {
+        b->cand_ms = 1e30f;
+        return;
+    }
+    b->cand_ms = std::min(b->cand_ms, ms);
+    if (b->samples < 3) return;
+    b->samples = 0;
+    const float step = 0.5f, max_split = 3.0f;
+    auto freeze = [&]() { b->cur = b->best; b->phase = 3; };
+    if (b->phase == 0) {
+        b->best_ms = b->cand_ms;
+        b->phase = 1;
+        if (b->best + step <= max_split) b->cur = b->best + step;
+        else if (b->best >= step) { b->phase = 2; b->cur = b->best - step; }
+        else freeze();
+        return;
+    }
+    const bool better = b->cand_ms < b->best_ms * 0.993f;
+    if (better) {
+        b->best = b->cur;
+        b->best_ms = b->cand_ms;
+        b->moved = 1;
+        const float next = b->phase == 1 ? b->cur + step : b->cur - step;
+        if (next < 0.0f || next > max_split || b->calls > 40) freeze();
+        else b->cur = next;
+    } else if (b->phase == 1 && !b->moved && b->best >= step) {
+        b->phase = 2;
+        b->cur = b->best - step;
+    } else {
+        freeze();
+    }
+}
+
 static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, Plan** out, int n_frames = 1 << 20) {
-    const float split = e->split_for(n_frames);
+    const vj_env::Balance* bal = balance_of(e, c, W, H, p, n_frames, false);
+    const float split = bal ? bal->cur : e->split_for(n_frames);
     const int small = small_frame_class(e, W, H, n_frames);
     vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
                         p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64)) | ((uint32_t)small << 8), f2u(split));
@@ -1008,6 +1062,9 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
             qa.q_in_count = qc[ps];
             qa.q_ticket = qc[0] + ps * Q_PARTS;   // queue 0 does not exist: its counters serve as tickets
             qa.thin_pass_spread = e->thin_pass_spread ? 1u : 0u;
+            // frame-major order inside a part: one slice per frame of the part's frame group (-1), or as configured
+            qa.q_slices = e->q_slices >= 0 ? (uint32_t)std::max(1, e->q_slices)
+                                           : (uint32_t)std::max(1, std::min(16, (nf + (int)Q_PARTS - 1) / (int)Q_PARTS));
             qa.min_chunk = (uint32_t)e->min_chunk;
             qa.wide_tail = (e->wide_tail < 0 ? nf <= 4 : e->wide_tail != 0) ? 1u : 0u;
             qa.q_out = last ? nullptr : (QEntry*)dq[ps + 1].p;
@@ -1733,6 +1790,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         e->min_chunk = std::max(1, std::min(atoi(value), 64));
         return VJ_OK;
     }
+    if (strcmp(key, "q_slices") == 0) {
+        e->q_slices = std::max(-1, std::min(atoi(value), 64));
+        return VJ_OK;
+    }
     if (strcmp(key, "thin_pass_spread") == 0) {
         e->thin_pass_spread = atoi(value) != 0;
         return VJ_OK;
@@ -1821,8 +1882,16 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         } else {
             e->tile_split_small = e->tile_split_mid = e->tile_split = std::max(0.0f, (float)atof(value));
         }
+        e->tile_split_set = true;      // the caller's values hold: no feedback
+        e->balance.clear();
         HIP_TRY(hipStreamSynchronize(e->stream));
         drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "auto_balance") == 0) {   // 1: find the chain balance of a batch workload from its first calls' times; "reset": start over
+        if (strcmp(value, "reset") == 0) e->tile_split_set = false;
+        else e->auto_balance = atoi(value) != 0;
+        e->balance.clear();
         return VJ_OK;
     }
     if (strcmp(key, "xcd_affinity") == 0) {
@@ -2048,6 +2117,7 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
     Plan* pl;
+    vj_env::Balance* bal = balance_of(e, c, W, H, *p, n_frames, true);   // (created before the plan is looked up: it names the split)
     rc = get_plan(e, c, W, H, *p, &pl, n_frames);
     if (rc) return rc;
     const uint64_t max_frames = max_frames_per_subbatch(e, pl);
@@ -2061,6 +2131,12 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
         rc = detect_subbatch(e, pl, frames, f0, nf, W, H, *p, &dets, &out->counters, &out->timing);
         if (rc) return rc;
     }
+    // feedback for the chain balance: only plans that run two chains, only the timed (uncounted) kernel variants
+    if (bal && pl->block_first > 0 && !pl->units.empty() && !(p->flags & VJ_FLAG_COUNTERS) && (uint64_t)n_frames <= max_frames)
+        balance_report(bal, out->timing.cascade_ms);
+    else if (bal && bal->phase != 3 && (pl->block_first == 0 || pl->units.empty()))
+        bal->phase = 3;      // one chain only: nothing to balance
+    out->timing.tile_split = pl->tile_split;
     return build_result(pl, dets, n_frames, *p, out);
 }
 
@@ -2439,7 +2515,9 @@ int vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int 
         vj_stream* s;
         ~Guard() { if (s) vj_stream_destroy(s); }
     } guard{nullptr};
-    int rc = build_plan(e, *c, width, height, *p, s->plan.get(), e->split_for(max_batch),
+    // (a chain balance already found for this workload by vj_detect's feedback is taken over; a stream does not search itself)
+    const vj_env::Balance* bal = balance_of(e, c, width, height, *p, max_batch, false);
+    int rc = build_plan(e, *c, width, height, *p, s->plan.get(), bal ? bal->best : e->split_for(max_batch),
                         TileThresholds{e->tile_min_windows, e->tile_accept_windows, e->tile_max_dwords_per_window});
     if (rc) {
         s->plan->release_device();

@@ -198,6 +198,17 @@ struct vj_env {
     uint32_t roi_unit_cap = 0, roi_det_cap = 0;
     typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t, uint32_t, uint32_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<vj::Plan>> plans;
+    // Chain balance per workload (cascade, frame size, parameters, batch size): how much tile work goes to the
+    // global-gather chain (Plan::tile_split) is found by a short hill climb on the measured cascade time of the first
+    // calls and then frozen; vj_env_configure("tile_split", ...) or ("auto_balance", "0") keep the static values.
+    struct Balance {
+        float cur = 0, best = 0, best_ms = 0, cand_ms = 0;
+        int phase = 0;        // 0: measuring the start value, 1: climbing up, 2: climbing down, 3: frozen
+        int samples = 0, moved = 0, calls = 0;
+    };
+    typedef std::tuple<PlanKey, int> BalanceKey;    // the plan key with split = 0, frames per call
+    std::map<BalanceKey, Balance> balance;
+    bool auto_balance = true, tile_split_set = false;
     typedef std::tuple<uint64_t, int, int, int, int, uint64_t> CvPlanKey;   // cascade uid, W, H, min size, bits of the scale factor
     std::map<CvPlanKey, std::unique_ptr<vj::CvPlan>> cv_plans;
     vj::DevBuf d_cv_det, d_cv_counts;   // vj_detect_opencv: detection list and counters
@@ -236,6 +247,7 @@ struct vj_env {
     bool rois_on_device = true;   // vj_detect_rois: one region pass on the frames' integral images (0: one vj_detect per region size)
     int wide_tail = -1;           // queue passes: several windows in flight in the stump-parallel tail (-1: batches of <= 4 frames)
     int min_chunk = 32;           // queue passes: smallest chunk of windows a wave draws when there are fewer than 64 per wave
+    int q_slices = -1;            // queue passes: slices of a part handed out frame-major (-1: one per frame of the part's frame group)
     bool thin_pass_spread = true; // queue passes with fewer chunks than waves: only the first workgroups draw tickets
     int sp_tail_max = 48;         // global-gather sweeps switch to the stump-parallel tail when a wave holds at most this many windows (0: never)
     int gather_pairs = -1;        // global-gather sweeps evaluate two stumps per step, all their gathers in flight together: 0 never, 1 for

@@ -1048,14 +1048,28 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
                 if (lane == 0) t = atomicAdd(a.q_ticket + part, 1u);
                 t = __builtin_amdgcn_readfirstlane(t);
             }
-            // ticket -> (scale, chunk): walk the part's scales
+            // ticket -> (scale, chunk): walk the part's scales.  The entries of a (scale, part) sub-queue arrive roughly
+            // frame by frame (the grid pass walks an XCD's eighth of the (frame, unit) list in order), so the walk goes
+            // through the part in q_slices slices of every scale's chunk range — slice j of ALL scales before slice j + 1
+            // of any: the waves of an XCD then work on about one frame's sum image at a time (8 MB) instead of sweeping
+            // the part's whole frame group (66 MB for 64 x 1080p) once per scale.  q_slices = 1: scale by scale.
             uint32_t slot = a.n_scales, c = t;
-            if (t < part_chunks)
-                for (slot = 0; slot < a.n_scales; ++slot) {
-                    const uint32_t n_chunks = (counts[slot * Q_PARTS + part] + chunk - 1u) / chunk;
-                    if (c < n_chunks) break;
-                    c -= n_chunks;
-                }
+            if (t < part_chunks) {
+                const uint32_t J = max(a.q_slices, 1u);
+                bool found = false;
+                for (uint32_t j = 0; j < J && !found; ++j)
+                    for (slot = 0; slot < a.n_scales; ++slot) {
+                        const uint32_t n_chunks = (counts[slot * Q_PARTS + part] + chunk - 1u) / chunk;
+                        const uint32_t lo = (j * n_chunks + J - 1u) / J, hi = ((j + 1u) * n_chunks + J - 1u) / J;
+                        if (c < hi - lo) {
+                            c += lo;
+                            found = true;
+                            break;
+                        }
+                        c -= hi - lo;
+                    }
+                if (!found) slot = a.n_scales;
+            }
             if (slot == a.n_scales) {   // this part is used up: steal from the next one
                 part = (part + 1u) & (Q_PARTS - 1u);
                 ++tries;

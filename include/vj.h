@@ -266,6 +266,8 @@ typedef struct vj_timing {     /* HIP-event times of the last vj_detect, ms     
     int32_t pass_stage_end[VJ_MAX_PASSES];
     int32_t n_launches;                      /* kernel launches of the cascade  */
     vj_launch launch[VJ_MAX_LAUNCHES];       /* each with its own HIP events    */
+    float tile_split;          /* vj_detect: scales' worth of tile work the plan of this call gave to the global-gather
+                                  chain ("tile_split"; found per workload by feedback unless configured) */
 } vj_timing;
 
 typedef struct vj_result {

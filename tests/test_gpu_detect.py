@@ -492,3 +492,28 @@ def test_reserve_then_detect_other_sizes(oracle, cascades):
             assert as_list(r.rects[r.rects["frame"] == 0]) == as_list(ro)
     finally:
         clodReleaseEnvironment(env2)
+
+
+def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
+    """vj_detect finds the chain balance of a batch workload (Plan::tile_split) by a short hill climb on the measured
+    cascade time of its first calls, then freezes it: every call of the search returns the same rectangles (the split only
+    moves work between the two chains), the split stops moving, and configuring tile_split by hand switches the feedback off."""
+    c, a = cascades("frontalface_default")
+    frames = synth.batch(12, 360, 640, seed0=300)
+    env.configure("auto_balance", "reset")
+    env.configure("auto_balance", "1")
+    first = env.detect(c, frames)
+    splits = []
+    for _ in range(48):
+        r = env.detect(c, frames)
+        assert np.array_equal(r.rects, first.rects)
+        splits.append(r.tile_split)
+    assert len(set(splits[-6:])) == 1 and all(0.0 <= s <= 3.0 for s in splits)
+    ro, _ = oracle.detect(a, frames[5])
+    assert as_list(first.rects[first.rects["frame"] == 5]) == as_list(ro)
+    env.configure("tile_split", "0,0.5,0.5")             # static values: the feedback is off
+    try:
+        assert {env.detect(c, frames).tile_split for _ in range(7)} == {0.5}
+        assert np.array_equal(env.detect(c, frames).rects, first.rects)
+    finally:
+        env.configure("auto_balance", "reset")

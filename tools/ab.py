@@ -9,7 +9,8 @@ B = int(sys.argv[3]) if len(sys.argv) > 3 else 64
 casc = sys.argv[4] if len(sys.argv) > 4 else "frontalface_alt"
 modes = sys.argv[5].split("/") if len(sys.argv) > 5 else ["1", "0"]
 env = Environment(0); c = Cascade.load(casc)
-t = torch.from_numpy(synth.batch(B, 1080, 1920, seed0=1)).cuda(); torch.cuda.synchronize()
+H, W = int(os.environ.get("H", "1080")), int(os.environ.get("W", "1920"))      # frame size: H=480 W=640 python tools/ab.py ...
+t = torch.from_numpy(synth.batch(B, H, W, seed0=1)).cuda(); torch.cuda.synchronize()
 df = DeviceFrames.from_torch(t)
 ref = None
 for conc in modes:
