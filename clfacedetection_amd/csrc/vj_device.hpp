@@ -253,7 +253,8 @@ struct RoiArgs {
     uint32_t* det_count;
     uint32_t det_cap;
 };
-int launch_roi_chain(const RoiArgs& r, const CascadeArgs& a, bool from_dets, bool trees, bool count, int n_blocks, void* stream);
+int launch_roi_chain(const RoiArgs& r, const CascadeArgs& a, bool from_dets, bool trees, bool count, bool general /* stage tree */,
+                     int n_blocks, void* stream);
 
 // Grouping of a first cascade's raw candidates on the device (vj_detect_chain with min_neighbors != 0): the grouped
 // rectangles become the region list of the second cascade without a host round trip (vj_group_dev.hip).

@@ -1455,8 +1455,8 @@ static void fill_region_args(vj_env* e, Lane* L, Plan* pl2, const vj_cascade* se
     ca.sum_bytes = (uint32_t)((uint64_t)pl2->frame_elems * 4u * (uint64_t)nf);
     ca.stride = stride;
     ca.stage_begin = 0;
-    ca.stage_end = (uint32_t)pl2->stages.size();
-    ca.identity_order = 1u;
+    ca.stage_end = pl2->general ? pl2->pass_bounds.back() : (uint32_t)pl2->stages.size();   // stage trees: positions in the sweep order
+    ca.identity_order = pl2->general ? 0u : 1u;
     ca.tree2 = 0u;
     ca.signed_mean = (p_second.flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
     ca.gather_pairs = 2u;   // regions are small: thin waves, latency-bound
@@ -1517,7 +1517,7 @@ static int detect_rois_on_device(vj_env* e, const vj_cascade* c, const vj_image*
             CascadeArgs ca;
             fill_region_args(e, L, pl2, c, *p, W, H, nf, n_reg, &ra, &ca);
             HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], e->stream));
-            const int hrc = launch_roi_chain(ra, ca, false, pl2->trees, count2, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
+            const int hrc = launch_roi_chain(ra, ca, false, pl2->trees, count2, pl2->general, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
             if (hrc) {
                 set_error("region pass launch failed: %s", hipGetErrorString((hipError_t)hrc));
                 return VJ_ERR_HIP;
@@ -2164,10 +2164,8 @@ int vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int n
         for (int i = 0; i < n_frames && same; ++i)
             same = frames[i].data && frames[i].width == frames[0].width && frames[i].height == frames[0].height &&
                    image_channels(frames[i]) == image_channels(frames[0]) && frames[i].stride >= frames[i].width * image_channels(frames[i]);
-        bool linear = true;
-        for (const auto& st : c->stages) linear = linear && st.next == -1;
         int W = 0, H = 0, CH = 0;
-        if (same && linear && check_frames(frames, n_frames, &W, &H, &CH) == VJ_OK) {
+        if (same && check_frames(frames, n_frames, &W, &H, &CH) == VJ_OK) {
             HIP_TRY(hipSetDevice(e->device));
             return detect_rois_on_device(e, c, frames, n_frames, rois, n_rois, p, W, H, out);
         }
@@ -2247,10 +2245,6 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
     // each region picks its own scales and grid on the device
     if ((rc = get_plan(e, second, W, H, *p_second, &pl2))) return rc;
     if ((rc = get_plan(e, first, W, H, *p_first, &pl1, n_frames))) return rc;   // (the cache may have evicted it for pl2: look it up again)
-    if (pl2->general) {
-        set_error("the second cascade of vj_detect_chain must be a linear cascade");
-        return VJ_ERR_UNSUPPORTED;
-    }
     const uint64_t max_frames = std::min(max_frames_per_subbatch(e, pl1), max_frames_per_subbatch(e, pl2));
     if (max_frames == 0) {
         set_error("a single frame exceeds the 32-bit offset range");
@@ -2333,7 +2327,7 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
                 }
                 HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 5, ga.overflow, 4, hipMemcpyDeviceToHost, e->stream));
             }
-            const int hrc = launch_roi_chain(ra, ca, !grouped, pl2->trees, count2, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
+            const int hrc = launch_roi_chain(ra, ca, !grouped, pl2->trees, count2, pl2->general, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
             if (hrc) {
                 set_error("region pass launch failed: %s", hipGetErrorString((hipError_t)hrc));
                 return VJ_ERR_HIP;

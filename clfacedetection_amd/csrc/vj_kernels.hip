@@ -856,10 +856,10 @@ __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t i
 // e.g. 0..4, chain 5,7,..,39, then chain 6,8,..,46: failing in the first chain jumps
 // BACK to stage 6); at stage s only the lanes whose target is s evaluate, the others
 // ride along.  Whole cascade in one pass.
-template <bool TREES, bool COUNT>
-__device__ __forceinline__ void run_stages_general(const CascadeArgs& a, rsrc_t img, QEntry* q, int32_t* tgt,
-                                                   uint32_t n, uint32_t scale_slot, uint32_t table_first,
-                                                   uint32_t lane) {
+// `emit(mask, mine, off)`: the lanes of `mask` fell off the tree's end (accepted); `mine` says whether this lane is one.
+template <bool TREES, bool COUNT, typename Emit>
+__device__ __forceinline__ void run_stages_general_to(const CascadeArgs& a, rsrc_t img, QEntry* q, int32_t* tgt,
+                                                      uint32_t n, uint32_t table_first, uint32_t lane, Emit emit) {
     kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + table_first;
     kptr<StageDev> stages = as_k(a.stages);
     for (uint32_t i = lane; i < n; i += 64u) tgt[i] = (int32_t)stages[a.stage_begin].order;
@@ -881,14 +881,7 @@ __device__ __forceinline__ void run_stages_general(const CascadeArgs& a, rsrc_t 
             if (here) t = (stage_sum_of<TREES>(GlobalImg{img}, tab, n_nodes, e.off, e.var) >= threshold) ? on_pass : on_fail;
             const bool keep = act && t >= 0;
             const unsigned long long acc_mask = __ballot(act && t == -1);  // accepted: falls off the tree's end
-            if (acc_mask != 0ull) {
-                const uint32_t cnt = (uint32_t)__popcll(acc_mask);
-                uint32_t g = 0;
-                if (lane == 0) g = atomicAdd(a.det_count, cnt);
-                g = __builtin_amdgcn_readfirstlane(g);
-                const uint32_t pos = g + mbcnt(acc_mask);
-                if (act && t == -1 && pos < a.det_cap) a.det[pos] = DetEntry{e.off, scale_slot};
-            }
+            if (acc_mask != 0ull) emit(acc_mask, act && t == -1, e.off);
             if (COUNT) entered += (uint32_t)__popcll(__ballot(here));
             const unsigned long long mask = __ballot(keep);
             __builtin_amdgcn_wave_barrier();
@@ -903,6 +896,19 @@ __device__ __forceinline__ void run_stages_general(const CascadeArgs& a, rsrc_t 
         if (COUNT && lane == 0 && entered != 0u) atomicAdd(a.stage_entered + s, (unsigned long long)entered);
         n = m;
     }
+}
+
+template <bool TREES, bool COUNT>
+__device__ __forceinline__ void run_stages_general(const CascadeArgs& a, rsrc_t img, QEntry* q, int32_t* tgt,
+                                                   uint32_t n, uint32_t scale_slot, uint32_t table_first,
+                                                   uint32_t lane) {
+    run_stages_general_to<TREES, COUNT>(a, img, q, tgt, n, table_first, lane, [&](unsigned long long acc_mask, bool mine, uint32_t off) {
+        uint32_t g = 0;
+        if (lane == 0) g = atomicAdd(a.det_count, (uint32_t)__popcll(acc_mask));
+        g = __builtin_amdgcn_readfirstlane(g);
+        const uint32_t pos = g + mbcnt(acc_mask);
+        if (mine && pos < a.det_cap) a.det[pos] = DetEntry{off, scale_slot};
+    });
 }
 
 template <bool FROM_GRID, bool TREES, bool LAST, bool COUNT, bool GENERAL, int NW = 1>
@@ -1252,9 +1258,10 @@ __global__ __launch_bounds__(256) void roi_plan_units(RoiArgs r, CascadeArgs a) 
     }
 }
 
-template <bool TREES, bool COUNT>
+template <bool TREES, bool COUNT, bool GENERAL>
 __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_roi_pass(RoiArgs r, CascadeArgs a) {
     __shared__ QEntry lds_q[WAVES_PER_BLOCK * UNIT_WINDOWS];
+    __shared__ int32_t lds_tgt[GENERAL ? WAVES_PER_BLOCK * UNIT_WINDOWS : 1];   // stage trees: the stage every queued window visits next
     const uint32_t lane = lane_id();
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     QEntry* q = lds_q + wib * UNIT_WINDOWS;
@@ -1300,6 +1307,20 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_roi_pass(RoiArgs
             n_q += (uint32_t)__popcll(mask);
         }
         __builtin_amdgcn_wave_barrier();
+        if (GENERAL) {
+            // a stage tree as the second cascade (tempcv.cpp:834-861): the per-window walk of run_stages_general, accepted
+            // windows going to the region pass's own detection list
+            run_stages_general_to<TREES, COUNT>(a, img, q, lds_tgt + wib * UNIT_WINDOWS, n_q, scales[slot].table_first, lane,
+                                                [&](unsigned long long acc_mask, bool mine, uint32_t off) {
+                uint32_t g = 0;
+                if (lane == 0) g = atomicAdd(r.det_count, (uint32_t)__popcll(acc_mask));
+                g = __builtin_amdgcn_readfirstlane(g);
+                const uint32_t pos = g + mbcnt(acc_mask);
+                if (mine && pos < r.det_cap) r.det[pos] = RoiDet{off, slot, roi};
+            });
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + scales[slot].table_first;
         const uint32_t n = sweep_stages<TREES, COUNT>(a, GlobalImg{img}, table, q, n_q, lane, a.stage_begin, a.stage_end);
         if (n != 0u) {
@@ -1313,18 +1334,25 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_roi_pass(RoiArgs
     }
 }
 
-int launch_roi_chain(const RoiArgs& r, const CascadeArgs& a, bool from_dets, bool trees, bool count, int n_blocks, void* stream_) {
+template <bool GENERAL>
+static void launch_roi_pass(const RoiArgs& r, const CascadeArgs& a, bool trees, bool count, dim3 g, dim3 b, hipStream_t stream) {
+    if (trees) {
+        if (count) hipLaunchKernelGGL((cascade_roi_pass<true, true, GENERAL>), g, b, 0, stream, r, a);
+        else       hipLaunchKernelGGL((cascade_roi_pass<true, false, GENERAL>), g, b, 0, stream, r, a);
+    } else {
+        if (count) hipLaunchKernelGGL((cascade_roi_pass<false, true, GENERAL>), g, b, 0, stream, r, a);
+        else       hipLaunchKernelGGL((cascade_roi_pass<false, false, GENERAL>), g, b, 0, stream, r, a);
+    }
+}
+
+int launch_roi_chain(const RoiArgs& r, const CascadeArgs& a, bool from_dets, bool trees, bool count, bool general, int n_blocks,
+                     void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     if (from_dets) hipLaunchKernelGGL(dets_to_rois, dim3(256), dim3(256), 0, stream, r);
     hipLaunchKernelGGL(roi_plan_units, dim3(512), dim3(256), 0, stream, r, a);
     dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
-    if (trees) {
-        if (count) hipLaunchKernelGGL((cascade_roi_pass<true, true>), g, b, 0, stream, r, a);
-        else       hipLaunchKernelGGL((cascade_roi_pass<true, false>), g, b, 0, stream, r, a);
-    } else {
-        if (count) hipLaunchKernelGGL((cascade_roi_pass<false, true>), g, b, 0, stream, r, a);
-        else       hipLaunchKernelGGL((cascade_roi_pass<false, false>), g, b, 0, stream, r, a);
-    }
+    if (general) launch_roi_pass<true>(r, a, trees, count, g, b, stream);
+    else launch_roi_pass<false>(r, a, trees, count, g, b, stream);
     return (int)hipGetLastError();
 }
 
