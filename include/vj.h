@@ -171,24 +171,20 @@ void vj_env_destroy(vj_env* e);
  * pre-size device buffers; optional — vj_detect grows them on demand.          */
 int  vj_env_reserve(vj_env* e, int max_w, int max_h, int max_batch);
 int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
-/* Tunables (results never depend on them): "pass_split" = comma-separated stage
- * indices at which the cascade is cut into separate launches ("" = default),
- * "blocks_per_cu" = persistent workgroups per CU of the global-gather passes,
- * "tile_classes_kb" = "a,b,c" LDS budgets of the image-tile launches ("0,0,0"
- * turns the LDS-tile path off), "tile_end" = stage at which tile launches stop,
- * "tile_min_windows" / "tile_accept_windows" = windows per tile that make a class
- * acceptable / a scale eligible for tiles, "tile_lds_reserve_kb" = LDS per CU left
- * to the global-gather chain, "concurrent" = 0/1 overlap the two chains on two
- * streams, "concurrent_blocks_per_cu", "tile_split" = scales' worth of tile work
- * handed to the gather chain (one value, or "small,mid,large" for batches of <= 4, < 32, >= 32 frames), "grid_block_w" = width of the 2-D window blocks of the
- * gather chain's first pass (0: row runs), "global_blocks" = 0/1 large scales as
- * unstaged blocks in the tile kernel, "tile_repack" = stages before which a tile
- * re-packs, "tile_finish" (0 stump-parallel only, 1 wave-split first),
- * "tile_sp_begin", "tile_sp_max", "tile_ws_min", "tile_ws_max" = finish
- * thresholds, "tile_deinterleave", "tile_min_lanes", "max_subbatch", "det_cap", "gather_pairs" (stumps per step of the
- * global-gather sweeps: 0 one, 1 two for thin waves, 2 two always, -1 by batch size), "sp_tail_max" (a wave of the gather
- * sweeps with at most this many windows left finishes stump-parallel; 0 never), "seg_cut2", "plan_cache_max", "thin_pass_spread" (0/1), "min_chunk" (queue passes: smallest chunk of windows a wave draws, 1..64), "wide_tail" (queue passes: two windows' gathers in flight in the stump-parallel tail; 0/1, -1 = batches of <= 4 frames), "rois_on_device" (0/1), "tree_split_queues" (0/1), "group_max"
- * (vj_detect_chain: raw candidates of one frame grouped on the device, <= 2048; a frame with more takes the host path).
+/* Tunables — speed only: results never depend on them (tests sweep every group).  One line per group here; every key
+ * with its values, default and the measurement behind the default is in DESIGN.md §7.
+ *   launch structure   pass_split, pass_cut_nodes, blocks_per_cu, concurrent, concurrent_blocks_per_cu, max_subbatch, det_cap
+ *   LDS tiles          tile_classes_kb, tile_lds_reserve_kb, tile_min_windows, tile_accept_windows, tile_end, tile_min_lanes,
+ *                      tile_max_dwords_per_window, tile_class_order, tile_lds_nest, tile_repack, tile_deinterleave, tile_stage_x4,
+ *                      global_blocks
+ *   tile finish        tile_finish, tile_sp_begin, tile_sp_max, tile_ws_min, tile_ws_max
+ *   chain balance      tile_split ("small,mid,large" or one value: static), auto_balance (1 / 0 / "reset": feedback on the
+ *                      first calls of a batch workload)
+ *   global-gather      grid_block_w, gather_pairs, sp_tail_max, wide_tail, min_chunk, thin_pass_spread, q_slices, xcd_affinity
+ *   stage trees        general_prefix, tile_segments, seg_cut2, tree_split_queues
+ *   regions / chain    rois_on_device, group_max
+ *   OpenCV profile     cv_tiles, cv_row_blocks, cv_tile_min_windows, cv_tile_min_windows0, cv_tile_ws_max
+ *   housekeeping       plan_cache_max
  * Unknown keys return VJ_ERR_ARG.                                               */
 int  vj_env_configure(vj_env* e, const char* key, const char* value);
 

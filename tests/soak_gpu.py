@@ -1,7 +1,8 @@
 """Randomized soak of the HIP path against the oracle — more cases than the test suite affords (run by hand on the GPU box:
 `python tests/soak_gpu.py [seconds] [first seed] [max width] [max height]`; not collected by pytest).  Every case draws a cascade, a frame kind
-and size, size limits, a scale factor, a mode (exhaustive grid, the CPU variants' skip sets, the OpenCV profile, the
-two-cascade chain with or without grouping), a batch size and a few tunables; rectangles and per-stage counts must equal
+and size, size limits, a scale factor, a mode (exhaustive grid, the four CPU variants' skip sets incl. the block variant's f64
+grids, the OpenCV profile on tiles and rows, the two-cascade chain with or without grouping, host-supplied regions incl. stage
+trees), a batch size and a few tunables; rectangles and per-stage counts must equal
 the oracle's.  Prints one line per failure and a summary; exit code 1 if anything differed."""
 import os
 import sys
@@ -17,7 +18,8 @@ try:
 except Exception:
     pass
 from cases import make_frame  # noqa: E402
-from clfacedetection_amd import (VJ_FLAG_COUNTERS, VJ_FLAG_SKIP_LIST, VJ_FLAG_SKIP_ROW, Cascade, Environment, default_params)  # noqa: E402
+from clfacedetection_amd import (VJ_FLAG_COUNTERS, VJ_FLAG_GRID_F64, VJ_FLAG_SKIP_LIST, VJ_FLAG_SKIP_ROW, Cascade, Environment,  # noqa: E402
+                                 default_params)
 from clfacedetection_amd.api import DATA_DIR  # noqa: E402
 from oracle.oracle import Oracle, load_vjc  # noqa: E402
 
@@ -32,9 +34,13 @@ CASC = {n: (Cascade.load(n), load_vjc(os.path.join(DATA_DIR, f"haarcascade_{n}.v
 TUNABLES = [("tile_split", ["0", "0.5", "1.3", "0,0.5,0.5"]), ("blocks_per_cu", ["1", "3", "8"]), ("gather_pairs", ["-1", "0", "2"]),
             ("sp_tail_max", ["0", "16", "48"]), ("thin_pass_spread", ["0", "1"]), ("tree_split_queues", ["0", "1"]), ("concurrent", ["0", "1"]),
             ("tile_classes_kb", ["-2,-1,0", "0,0,0", "24,40,60"]), ("grid_block_w", ["0", "32"]), ("max_subbatch", ["0", "2"]),
-            ("group_max", ["2048", "30"]), ("rois_on_device", ["1", "0"]), ("wide_tail", ["-1", "0", "1"]), ("min_chunk", ["32", "64", "5"])]
+            ("group_max", ["2048", "30"]), ("rois_on_device", ["1", "0"]), ("wide_tail", ["-1", "0", "1"]), ("min_chunk", ["32", "64", "5"]),
+            ("q_slices", ["-1", "1", "5"]), ("cv_tiles", ["1", "0"]), ("cv_tile_ws_max", ["512", "100", "0"]), ("cv_row_blocks", ["3", "1"]),
+            ("cv_tile_min_windows", ["1536", "256", "64"]), ("cv_tile_min_windows0", ["2048", "512", "64"]), ("auto_balance", ["1", "0"])]
 DEFAULTS = {"tile_split": "0,0.5,0.5", "blocks_per_cu": "8", "gather_pairs": "-1", "sp_tail_max": "48", "thin_pass_spread": "1", "tree_split_queues": "1",
-            "concurrent": "1", "tile_classes_kb": "-2,-1,0", "grid_block_w": "32", "max_subbatch": "0", "group_max": "2048", "rois_on_device": "1", "wide_tail": "-1", "min_chunk": "32"}
+            "concurrent": "1", "tile_classes_kb": "-2,-1,0", "grid_block_w": "32", "max_subbatch": "0", "group_max": "2048", "rois_on_device": "1", "wide_tail": "-1", "min_chunk": "32",
+            "q_slices": "-1", "cv_tiles": "1", "cv_tile_ws_max": "512", "cv_row_blocks": "3", "cv_tile_min_windows": "1536", "cv_tile_min_windows0": "2048",
+            "auto_balance": "1"}
 
 
 def rows(r):
@@ -47,14 +53,15 @@ by_mode = {}
 seed = seed0
 while time.time() < t_end:
     rng = np.random.default_rng(770000 + seed)
-    mode = ["grid", "grid", "grid", "skip_list", "skip_row", "opencv", "chain", "chain_grouped", "rois"][int(rng.integers(0, 9))]
+    mode = ["grid", "grid", "grid", "skip_list", "skip_row", "block_row", "block_list", "opencv", "opencv", "chain", "chain_grouped", "rois",
+            "rois"][int(rng.integers(0, 13))]
     name = NAMES[int(rng.integers(0, len(NAMES)))]
     c, a = CASC[name]
     linear = bool(np.all(a.stage_next == -1))
     tilted = bool(a.node_tilted.any())
     if tilted and mode != "opencv":
         mode = "opencv"
-    if mode in ("skip_list", "skip_row") and not linear:
+    if mode in ("skip_list", "skip_row", "block_row", "block_list") and not linear:
         mode = "grid"
     w = int(rng.integers(c.info.win_w + 11, max_w))
     h = int(rng.integers(c.info.win_h + 11, max_h))
@@ -72,14 +79,15 @@ while time.time() < t_end:
     desc = (seed, mode, name, kind, h, w, nb, tun)
     ok = True
     try:
-        if mode in ("grid", "skip_list", "skip_row"):
+        if mode in ("grid", "skip_list", "skip_row", "block_row", "block_list"):
             mn = (0, 0) if rng.random() < 0.6 else (int(rng.integers(20, 70)),) * 2
             mx = (0, 0) if rng.random() < 0.7 else (int(rng.integers(80, 300)),) * 2
             sf = [1.1, 1.2, 1.05, 1.3, 1.5][int(rng.integers(0, 5))]
-            flags = VJ_FLAG_COUNTERS | {"grid": 0, "skip_list": VJ_FLAG_SKIP_LIST, "skip_row": VJ_FLAG_SKIP_ROW}[mode]
+            flags = VJ_FLAG_COUNTERS | {"grid": 0, "skip_list": VJ_FLAG_SKIP_LIST, "skip_row": VJ_FLAG_SKIP_ROW,
+                                        "block_row": VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64, "block_list": VJ_FLAG_SKIP_LIST | VJ_FLAG_GRID_F64}[mode]
             p = default_params(flags=flags, min_w=mn[0], min_h=mn[1], max_w=mx[0], max_h=mx[1], scale_factor=sf)
             r = env.detect(c, [img] * nb if nb > 1 else img, p)
-            ro, st = o.detect(a, img, min_size=mn, max_size=mx, scale_factor=sf, mode={"grid": None, "skip_list": 2, "skip_row": 3}[mode])
+            ro, st = o.detect(a, img, min_size=mn, max_size=mx, scale_factor=sf, mode={"grid": None, "skip_list": 2, "skip_row": 3, "block_row": 4, "block_list": 5}[mode])
             for f in range(nb):
                 ok &= rows(r.rects[r.rects["frame"] == f]) == rows(ro)
             ok &= r.stage_entered == [v * nb for v in st["stage_entered"]]
@@ -94,7 +102,7 @@ while time.time() < t_end:
             ok &= r.stage_entered == [v * nb for v in st["stage_entered"]] and r.windows == st["windows"] * nb
             desc += (mn, sf)
         elif mode == "rois":                      # host-supplied regions of random sizes in a small batch
-            if not linear:
+            if tilted:                            # (stage trees are welcome: the region pass walks them)
                 name = "eye"
                 c, a = CASC[name]
             imgs = [img, make_frame(kind, 9100 + seed, h, w)][:max(1, min(nb, 2))]

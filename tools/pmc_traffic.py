@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_hash
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 os.makedirs("profiles", exist_ok=True)
 
 def per_kernel(d, counters):
@@ -27,6 +27,9 @@ def per_kernel(d, counters):
 
 for f in glob.glob(f"{src}/kt/*/*kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
+for cfg in ("config2", "config4", "config5", "cv"):      # the other configs' kernel-trace summaries (tools/configs.py under rocprofv3)
+    for f in glob.glob(f"{src}/kt_{cfg}/*/*kernel_stats.csv"):
+        shutil.copy(f, f"profiles/{tag}_{cfg}_kernel_stats.csv")
 fetch, write = per_kernel("fetch", {"FETCH_SIZE"}), per_kernel("write", {"WRITE_SIZE"})
 SQ = ("SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_WAVE_CYCLES", "SQ_BUSY_CYCLES",
       "SQ_WAIT_ANY", "SQ_INSTS_VALU")
@@ -52,7 +55,7 @@ for k in sorted(set(fetch) | set(write) | set(sq)):
 json.dump(out, open(f"profiles/{tag}_pmc_traffic.json", "w"), indent=1)
 # dominant kernel = most total time in the kernel stats
 stats = [r for r in csv.DictReader(open(f"profiles/{tag}_kernel_stats.csv"))
-         if "cv_profile_pass" not in r["Name"]]      # the OpenCV profile is a second path, measured in the same bench run
+         if "cv_profile_pass" not in r["Name"] and "cv_tile_pass" not in r["Name"]]      # the OpenCV profile is a second path, measured in the same bench run
 stats.sort(key=lambda r: -float(r["TotalDurationNs"]))
 dom = stats[0]["Name"]
 kind = "tile" if "cascade_tile_pass" in dom else ("grid" if "cascade_pass<true" in dom else "queue")
