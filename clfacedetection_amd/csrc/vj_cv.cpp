@@ -84,6 +84,15 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
             hs.push_back(s);
         }
     }
+    // stage trees: the tiles run the tree's linear prefix — leading stages of the sweep order that reject outright and pass
+    // on to the next one (cv_profile_pass finds the same prefix) — when the prefix is stages 0, 1, 2, ... themselves
+    uint32_t tree_prefix = 0;
+    if (is_tree) {
+        while (tree_prefix + 1u < order.size() && order[tree_prefix] == tree_prefix && prog.on_fail[tree_prefix] == STAGE_REJECT &&
+               prog.on_pass[tree_prefix] == (int)order[tree_prefix + 1u])
+            ++tree_prefix;
+    }
+    pl->tree_prefix = tree_prefix;
     const size_t n_nodes = c->nodes.size();
     std::vector<CvScaleDev>& scales = pl->scales;
     scales.assign(hs.size(), CvScaleDev{});
@@ -185,7 +194,7 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
         // windows (tw divides 64, so a tile row never straddles a word of the reject / visited bitmap); its footprint is
         // the span of its window origins plus the furthest corner any feature or the equRect reaches.  Two LDS classes
         // like the clod profile's tiles: two workgroups per CU or one, next to one workgroup of cv_profile_pass.
-        if (e->cv_tiles && !trees && !is_tree && !has_tilted && sd.end_x < 65536u && sd.end_y < 65536u) {
+        if (e->cv_tiles && !trees && (!is_tree || tree_prefix != 0u) && !has_tilted && sd.end_x < 65536u && sd.end_y < 65536u) {
             uint32_t reach_x = (uint32_t)(ex + ew), reach_y = (uint32_t)(ex + eh);
             for (size_t n = 0; n < n_nodes; ++n) {
                 const CvNodeRec& r = recs[n];
@@ -249,6 +258,7 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
             CvScaleDev& sd = scales[k];
             if (sd.tile_th == 0u) continue;
             ++pl->n_tile_scales;
+            pl->tile_windows += (uint64_t)sd.end_x * sd.end_y;
             sd.bits_base = word;
             const uint32_t wpr = (sd.end_x + 63u) / 64u;
             for (uint32_t iy = 0; iy < sd.end_y; ++iy) bit_segs.push_back(UnitDev{(uint32_t)k, word + iy * wpr, wpr, 0});
@@ -396,7 +406,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
     DevBuf& d_det = e->d_cv_det;
     DevBuf& d_counts = e->d_cv_counts;
     // counters: stage_entered[VJ_MAX_STAGES] | visited | ... | detection count | pad | 4 x 8 tile ticket counters
-    const size_t counts_bytes = 2 * VJ_MAX_STAGES * sizeof(uint64_t) + 16 + 4 * 8 * sizeof(uint32_t);
+    const size_t counts_bytes = 2 * VJ_MAX_STAGES * sizeof(uint64_t) + 16 + 4 * 8 * sizeof(uint32_t) + 16;   // ... | tree-queue count
     if ((rc = d_counts.ensure(counts_bytes))) return rc;
 
     const bool count = (p->flags & VJ_FLAG_COUNTERS) != 0;
@@ -416,6 +426,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
         if ((rc = enqueue_integral(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf, CH))) return rc;
         if (has_tilted && (rc = enqueue_tilted(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf, CH))) return rc;
         HIP_TRY(hipEventRecord(e->lane0.ev[1], e->stream));
+        bool rows_only = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             if ((rc = d_det.ensure((size_t)det_cap * sizeof(CvDet)))) return rc;
             HIP_TRY(hipMemsetAsync(d_counts.p, 0, counts_bytes, e->stream));
@@ -441,8 +452,108 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             a.stage_entered = (unsigned long long*)d_counts.p;
             HIP_TRY(hipEventRecord(e->lane0.ev[2], e->stream));
             int hrc = 0;
-            const bool tiles = pl->n_tile_scales != 0 && pl->class_first[2] != 0;
-            if (tiles) {
+            // (a stage tree's tile path leaves no per-stage counts of the visited windows: counted calls walk the rows)
+            const bool tiles = pl->n_tile_scales != 0 && pl->class_first[2] != 0 && !(is_tree && (count || rows_only));
+            uint32_t tq_cap = 0;
+            if (tiles && is_tree) {
+                // Stage tree: the tiles run the linear prefix on every grid window (cv_tile_pass<2>), cv_tree_walk the rest of the
+                // tree for the survivors, skip_resolve + cv_tree_emit the sequential walk.  cv_profile_pass keeps the large scales.
+                const size_t bits_bytes = (size_t)pl->bits_frame_words * 8u * (size_t)nf;
+                if ((rc = e->d_skip_bits.ensure(bits_bytes))) return rc;
+                if ((rc = e->d_cv_accept.ensure(bits_bytes))) return rc;
+                tq_cap = (uint32_t)std::min<uint64_t>(pl->tile_windows * (uint64_t)nf / 4u + 4096u, 1ull << 27);
+                if ((rc = e->d_cv_tq.ensure((size_t)tq_cap * sizeof(CvTreeEntry)))) return rc;
+                HIP_TRY(hipMemsetAsync(e->d_skip_bits.p, 0, bits_bytes, e->stream));
+                HIP_TRY(hipMemsetAsync(e->d_cv_accept.p, 0, bits_bytes, e->stream));
+                const bool two = e->concurrent && pl->n_rows_rest != 0;
+                hipStream_t sB = two ? e->stream2 : e->stream;
+                if (two) {
+                    HIP_TRY(hipEventRecord(e->fork_ev, e->stream));
+                    HIP_TRY(hipStreamWaitEvent(e->stream2, e->fork_ev, 0));
+                }
+                if (pl->n_rows_rest != 0) {
+                    CvArgs b = a;
+                    b.rows = (const UnitDev*)pl->d_rows_rest.p;
+                    b.n_rows = pl->n_rows_rest;
+                    const int nb = std::max(1, e->n_cu * (two ? e->cv_row_blocks : 4));
+                    b.total_waves = (uint32_t)nb * CV_WAVES_PER_BLOCK;
+                    hrc = launch_cv_profile_pass(b, trees, false, true, nb, sB);
+                }
+                uint32_t* tickets = a.det_count + 4;
+                uint32_t* tq_count = tickets + 32;
+                CvTileArgs t;
+                memset(&t, 0, sizeof(t));
+                t.sum = a.sum;
+                t.sqsum = a.sqsum;
+                t.table = a.table;
+                t.scales = a.scales;
+                t.stages = a.stages;
+                t.n_frames = (uint32_t)nf;
+                t.n_stages = pl->tree_prefix;        // the tiles stop after the prefix
+                t.frame_elems = frame_elems;
+                t.stride = stride;
+                t.sum_h = a.sum_h;
+                t.bits = (unsigned long long*)e->d_skip_bits.p;
+                t.bits_frame_words = pl->bits_frame_words;
+                t.repack_mask = ~3ull;
+                t.ws_begin = 0xffffffffu;            // no finish: whoever survives the prefix leaves the tile
+                t.ws_max = 0;
+                t.det = a.det;
+                t.det_count = a.det_count;
+                t.det_cap = det_cap;
+                t.tq = (CvTreeEntry*)e->d_cv_tq.p;
+                t.tq_count = tq_count;
+                t.tq_cap = tq_cap;
+                for (int cls = 0; cls < 2 && !hrc; ++cls) {
+                    const uint32_t n_cls = pl->class_first[cls + 1] - pl->class_first[cls];
+                    if (!n_cls) continue;
+                    CvTileArgs ta = t;
+                    ta.tiles = (const UnitDev*)pl->d_tiles.p + pl->class_first[cls];
+                    ta.n_tiles = n_cls;
+                    ta.lds_bytes = pl->class_lds[cls];
+                    ta.ticket = tickets + 8 * cls;
+                    const int per_cu = std::max(1, std::min(2, (int)((160u * 1024u - (uint32_t)e->cv_row_blocks * 20u * 1024u) / ta.lds_bytes)));
+                    const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
+                    hrc = launch_cv_tile_pass(ta, 2, false, std::max(1, tb), e->stream);
+                }
+                CvTreeArgs w;
+                memset(&w, 0, sizeof(w));
+                w.sum = a.sum;
+                w.table = a.table;
+                w.scales = a.scales;
+                w.stages = a.stages;
+                w.n_order = pl->n_order;
+                w.prefix = pl->tree_prefix;
+                w.sum_bytes = (uint32_t)((uint64_t)frame_elems * 4u * (uint64_t)nf);
+                w.tq = (const CvTreeEntry*)e->d_cv_tq.p;
+                w.tq_count = tq_count;
+                w.tq_cap = tq_cap;
+                w.reject = (unsigned long long*)e->d_skip_bits.p;
+                w.accept = (unsigned long long*)e->d_cv_accept.p;
+                w.bits_frame_words = pl->bits_frame_words;
+                w.n_frames = (uint32_t)nf;
+                w.segs = (const UnitDev*)pl->d_bit_segs.p;
+                w.n_segs = pl->n_bit_segs;
+                w.det = a.det;
+                w.det_count = a.det_count;
+                w.det_cap = det_cap;
+                if (!hrc) hrc = launch_cv_tree_walk(w, std::max(1, e->n_cu * 4), e->stream);
+                if (!hrc) {
+                    CascadeArgs ra;
+                    memset(&ra, 0, sizeof(ra));
+                    ra.skip_bits = (unsigned long long*)e->d_skip_bits.p;
+                    ra.skip_frame_words = pl->bits_frame_words;
+                    ra.skip_segs = (const UnitDev*)pl->d_bit_segs.p;
+                    ra.n_skip_segs = pl->n_bit_segs;
+                    ra.n_frames = (uint32_t)nf;
+                    hrc = launch_skip_resolve(ra, std::max(1, e->n_cu * 2), e->stream);
+                }
+                if (!hrc) hrc = launch_cv_tree_emit(w, std::max(1, e->n_cu * 2), e->stream);
+                if (two) {
+                    HIP_TRY(hipEventRecord(e->join_ev, e->stream2));
+                    HIP_TRY(hipStreamWaitEvent(e->stream, e->join_ev, 0));
+                }
+            } else if (tiles) {
                 // The small scales on LDS tiles (vj_cv_tile.hip), the rest on cv_profile_pass, concurrently on two streams:
                 // the row kernel is bound by the texture-address unit, the tile kernel by LDS and VALU.  The row kernel is
                 // launched first with one workgroup per CU so that the tile workgroups find their LDS share next to it.
@@ -528,6 +639,12 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             HIP_TRY(hipMemcpyAsync(h.data(), d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));
             const uint32_t n_det = (uint32_t)(h[2 * VJ_MAX_STAGES] & 0xffffffffull);
+            const uint32_t n_tq = ((const uint32_t*)(h.data() + 2 * VJ_MAX_STAGES))[4 + 32];
+            if (tq_cap != 0u && n_tq > tq_cap) {   // more prefix survivors than the tree queue holds (a quarter of the windows): rows only
+                rows_only = true;
+                --attempt;
+                continue;
+            }
             if (n_det > det_cap) {   // overflow: grow and redo this sub-batch's cascade
                 while (det_cap < n_det) det_cap *= 2;
                 continue;

@@ -408,6 +408,84 @@ int launch_cv_profile_pass(const CvArgs& a, bool trees, bool count, bool stage_t
     return (int)hipGetLastError();
 }
 
+// ------------------------------------------------------------------------ stage trees whose prefix ran on LDS tiles
+// cv_tile_pass<2> (vj_cv_tile.hip) evaluated the tree's linear prefix on every grid window of the small scales and queued
+// the survivors.  cv_tree_walk takes them the rest of the way (tempcv.cpp:834-861: pass -> child, fail -> the next
+// sibling up the tree, else reject; the stages are swept once in topological order, every lane carrying the stage it
+// visits next) and sets each window's reject or accept bit; after skip_resolve has turned the reject bits of every
+// window row into visited bits, cv_tree_emit reports the accepted windows the sequential walk visits.
+__global__ __launch_bounds__(256) void cv_tree_walk(CvTreeArgs a) {
+    const uint32_t lane = lane_id();
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    kptr<StageDev> stages = as_k(a.stages);
+    kptr<CvScaleDev> scales = as_k(a.scales);
+    const rsrc_t img = make_rsrc(a.sum, a.sum_bytes);
+    const uint32_t n = min(*a.tq_count, a.tq_cap);
+    for (uint32_t base = wave * 64u; base < n; base += n_waves * 64u) {
+        const bool act = base + lane < n;
+        const CvTreeEntry e = a.tq[act ? base + lane : base];
+        const uint32_t my_slot = e.bit_slot >> 8;
+        int32_t ptr = act ? stages[stages[a.prefix - 1u].order].on_pass : -3;   // what passing the prefix's last stage leads to
+        unsigned long long todo = __ballot(act);
+        while (todo != 0ull) {   // the entries of one scale at a time: the feature table must be wave-uniform
+            const uint32_t slot = (uint32_t)__builtin_amdgcn_readlane((int)my_slot, (int)__builtin_ctzll(todo));
+            const bool mine = act && my_slot == slot;
+            todo &= ~__ballot(mine);
+            kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + scales[slot].table_first;
+            for (uint32_t oi = a.prefix; oi < a.n_order; ++oi) {
+                const uint32_t s = stages[oi].order;
+                const bool here = mine && ptr == (int32_t)s;
+                if (__ballot(here) == 0ull) continue;
+                if (here) {
+                    const bool pass = cv_stage_sum<false, false>(img, img, table + stages[s].first_node, stages[s].n_nodes, e.off, e.vnf) >=
+                                      (double)stages[s].threshold;
+                    ptr = pass ? stages[s].on_pass : stages[s].on_fail;
+                }
+            }
+        }
+        if (act) {
+            const unsigned long long bit = 1ull << (e.bit_slot & 63u);
+            if (ptr == -1) atomicOr(a.accept + e.word, bit);
+            else atomicOr(a.reject + e.word, bit);   // -2, or a stage the sweep order never reaches: rejected
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void cv_tree_emit(CvTreeArgs a) {
+    const uint32_t lane = lane_id();
+    const uint32_t wave = blockIdx.x * 4u + (threadIdx.x >> 6), n_waves = gridDim.x * 4u;
+    kptr<UnitDev> segs = as_k(a.segs);
+    kptr<CvScaleDev> scales = as_k(a.scales);
+    const uint32_t total = a.n_segs * a.n_frames;
+    for (uint32_t u = wave; u < total; u += n_waves) {
+        const uint32_t frame = u / a.n_segs, r = u - frame * a.n_segs;
+        const uint32_t slot = segs[r].scale, first = segs[r].first, wpr = segs[r].count;
+        const uint32_t iy = (first - scales[slot].bits_base) / wpr;
+        const double ystep = scales[slot].ystep;
+        const uint32_t y = (uint32_t)cv_round((double)iy * ystep);
+        const size_t w0 = (size_t)frame * a.bits_frame_words + first;
+        for (uint32_t w = 0; w < wpr; ++w) {
+            const unsigned long long hits = a.accept[w0 + w] & a.reject[w0 + w];   // (reject holds the VISITED bits by now)
+            if (hits == 0ull) continue;   // uniform
+            const bool hit = ((hits >> lane) & 1ull) != 0ull;
+            uint32_t g = 0;
+            if (lane == 0) g = atomicAdd(a.det_count, (uint32_t)__popcll(hits));
+            g = __builtin_amdgcn_readfirstlane(g);
+            const uint32_t pos = g + mbcnt(hits);
+            if (hit && pos < a.det_cap) a.det[pos] = CvDet{(uint32_t)cv_round((double)(w * 64u + lane) * ystep), y, slot, frame};
+        }
+    }
+}
+
+int launch_cv_tree_walk(const CvTreeArgs& a, int n_blocks, void* stream_) {
+    hipLaunchKernelGGL(cv_tree_walk, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
+int launch_cv_tree_emit(const CvTreeArgs& a, int n_blocks, void* stream_) {
+    hipLaunchKernelGGL(cv_tree_emit, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------ tilted integral
 // cvIntegral's tilted sum (OpenCV 2.4.2 imgproc; tilted(X, Y) = sum of gray(x, y) over y < Y, |x - X + 1| <= Y - y - 1)
 // by its row recurrence

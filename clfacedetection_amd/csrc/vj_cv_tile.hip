@@ -20,6 +20,7 @@
 namespace vj {
 
 __device__ __forceinline__ void cvt_barrier() { __syncthreads(); }
+constexpr uint32_t CVT_OFF_MASK = 0xfffffu;   // a queue entry: tile-local byte offset (< 2^18) | window index inside the tile << 20 (mode 2)
 __device__ __forceinline__ int cvt_round(double v) { return __double2int_rn(v); }   // cvRound: half to even
 
 // CvNodeRec as 16 scalar dwords: lt[3] 0-2, da[3] 3-5, db[3] 6-8, w[3] 9-11, thr 12, left 13, right 14, flags 15
@@ -157,12 +158,13 @@ __device__ __forceinline__ uint32_t cvt_sweep(const char* img, kptr<NodeRecDev> 
     uint32_t m = 0, base = 0;
     auto group = [&](auto nc_tag) {
         constexpr int NC = decltype(nc_tag)::value;
-        uint32_t off[NC];
+        uint32_t raw[NC], off[NC];
         double vnf[NC], sum[NC];
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
             const uint32_t i = base + (uint32_t)c * 64u + lane;
-            off[c] = qo[i < n ? i : 0u];
+            raw[c] = qo[i < n ? i : 0u];
+            off[c] = raw[c] & CVT_OFF_MASK;   // (stage trees keep the window's index inside the tile above the offset)
             vnf[c] = qv[i < n ? i : 0u];
         }
         cvt_stage_sum_mode<NC>(img, tab, n_nodes, f64, off, vnf, sum);
@@ -172,7 +174,7 @@ __device__ __forceinline__ uint32_t cvt_sweep(const char* img, kptr<NodeRecDev> 
             const bool pass = base + (uint32_t)c * 64u + lane < n && sum[c] >= thr;
             const unsigned long long mask = __ballot(pass);
             if (pass) {
-                qo[m + mbcnt(mask)] = off[c];
+                qo[m + mbcnt(mask)] = raw[c];
                 qv[m + mbcnt(mask)] = vnf[c];
             }
             m += (uint32_t)__popcll(mask);
@@ -306,12 +308,17 @@ __device__ __forceinline__ uint32_t cvt_wave_split(const CvTileArgs& a, const ch
 }
 
 // MODE 0: reject bits of stage 0 for every grid window of the tile.  MODE 1: the cascade on the visited windows.
+// MODE 2 (stage trees; tempcv.cpp:834-861 returns 0 on ANY reject, so the skip rule needs the whole tree's verdict for
+// every grid window): the tree's linear prefix — a.n_stages stages, 95 % of the rejects — on every grid window of the
+// tile; a window's reject bit starts set and is cleared when it survives the prefix; the survivors go to a global queue
+// for cv_tree_walk (vj_cv_profile.hip), which sets their reject or accept bit; skip_resolve and cv_tree_emit follow.
 template <int MODE, bool COUNT>
 __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
     uint32_t* lds_off = lds_dyn;                                                              // [CVT_WAVES][CVT_WAVE_CAP]
     double* lds_vnf = reinterpret_cast<double*>(lds_dyn + CVT_WAVES * CVT_WAVE_CAP);          // [CVT_WAVES][CVT_WAVE_CAP]
     uint32_t* lds_cnt = lds_dyn + CVT_WAVES * CVT_WAVE_CAP * 3;                               // 64 dwords
+    unsigned long long* lds_F = reinterpret_cast<unsigned long long*>(lds_cnt + 64);           // mode 2: reject bits of the tile's <= 32 rows
     uint32_t* lds_img = lds_dyn + CVT_LDS_HEADER / 4;
     const uint32_t lane = lane_id();
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -403,6 +410,10 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
                 if (COUNT) n_visited += (uint32_t)__popcll(__ballot(take));
             }
             w_eval[k] = take && !border;
+            if (MODE == 2) {   // every evaluated window counts as rejected until it survives the prefix
+                const unsigned long long E = __ballot(w_eval[k]);
+                if (lane == 0 && ty < 32u) lds_F[ty] = E;
+            }
             w_off[k] = 0u;
             w_q[k] = 0ull;
             if (w_eval[k]) {
@@ -455,7 +466,8 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
             for (int k = 0; k < NCH; ++k) {
                 const unsigned long long mask = __ballot(w_eval[k]);
                 if (w_eval[k]) {
-                    qo[n + mbcnt(mask)] = w_off[k];
+                    const uint32_t tidx = (wib * (uint32_t)NCH + (uint32_t)k) * 64u + lane;   // row * 64 + column inside the tile
+                    qo[n + mbcnt(mask)] = MODE == 2 ? w_off[k] | (tidx << 20) : w_off[k];
                     qv[n + mbcnt(mask)] = w_vnf[k];
                 }
                 n += (uint32_t)__popcll(mask);
@@ -522,7 +534,34 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
                                   n, lane);
                 }
             }
-            if (!finished && n != 0u) flush(qo, n);
+            if (MODE == 2) {
+                // survivors of the prefix: clear their reject bits, hand them to the tree walk; then the rows' words go out
+                cvt_barrier();   // (lds_F is complete: every wave wrote its rows before the first sweep barrier... and none re-packs any more)
+                if (n != 0u) {
+                    uint32_t g = 0;
+                    if (lane == 0) g = atomicAdd(a.tq_count, n);
+                    g = __builtin_amdgcn_readfirstlane(g);
+                    for (uint32_t i = lane; i < n; i += 64u) {
+                        const uint32_t raw = qo[i], tidx = raw >> 20, lo = (raw & CVT_OFF_MASK) >> 2;
+                        const uint32_t ty = tidx >> 6, tx = tidx & 63u;
+                        atomicAnd(&lds_F[ty], ~(1ull << tx));
+                        const uint32_t ly = lo / pitch, lx = lo - ly * pitch;
+                        const uint32_t ix = ix0 + tx, iy = iy0 + ty;
+                        if (g + i < a.tq_cap)
+                            a.tq[g + i] = CvTreeEntry{frame * frame_bytes4 + ((y0 + ly) * a.stride + (x0 + lx)) * 4u,
+                                                      frame * a.bits_frame_words + scales[slot].bits_base + iy * wpr + (ix >> 6), (ix & 63u) | (slot << 8),
+                                                      0u, qv[i]};
+                    }
+                }
+                cvt_barrier();
+                for (uint32_t ty = threadIdx.x; ty < th; ty += (uint32_t)CVT_WAVES * 64u)
+                    if (iy0 + ty < end_y) {
+                        unsigned long long* word = bits + (iy0 + ty) * wpr + (ix0 >> 6);
+                        const unsigned long long F = lds_F[ty];
+                        if (tw == 64u) *word = F;
+                        else if (F != 0ull) atomicOr(word, F << (ix0 & 63u));
+                    }
+            } else if (!finished && n != 0u) flush(qo, n);
         }
         cvt_barrier();   // the tile is finished: lds_cnt may carry the next ticket
         if (threadIdx.x == 0) lds_cnt[40] = next_u;
@@ -533,7 +572,8 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
 
 int prepare_cv_tile_kernels() {
     const int max_lds = 160 * 1024;
-    const void* fns[] = {(const void*)cv_tile_pass<0, false>, (const void*)cv_tile_pass<1, false>, (const void*)cv_tile_pass<1, true>};
+    const void* fns[] = {(const void*)cv_tile_pass<0, false>, (const void*)cv_tile_pass<1, false>, (const void*)cv_tile_pass<1, true>,
+                         (const void*)cv_tile_pass<2, false>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         if (e != hipSuccess) return (int)e;
@@ -545,6 +585,7 @@ int launch_cv_tile_pass(const CvTileArgs& a, int mode, bool count, int n_blocks,
     hipStream_t stream = (hipStream_t)stream_;
     dim3 g(n_blocks), b(CVT_WAVES * 64);
     if (mode == 0) hipLaunchKernelGGL((cv_tile_pass<0, false>), g, b, a.lds_bytes, stream, a);
+    else if (mode == 2) hipLaunchKernelGGL((cv_tile_pass<2, false>), g, b, a.lds_bytes, stream, a);
     else if (count) hipLaunchKernelGGL((cv_tile_pass<1, true>), g, b, a.lds_bytes, stream, a);
     else hipLaunchKernelGGL((cv_tile_pass<1, false>), g, b, a.lds_bytes, stream, a);
     return (int)hipGetLastError();

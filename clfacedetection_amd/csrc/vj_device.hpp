@@ -362,7 +362,7 @@ int launch_cv_profile_pass(const CvArgs& a, bool trees, bool count, bool stage_t
 constexpr int CVT_WAVES = 8;            // waves per workgroup
 constexpr int CVT_WAVE_CAP = 256;       // windows (queue entries) per wave: four tile rows of <= 64 windows
 constexpr int CVT_WS_MAX = 512;         // windows a tile may carry into the wave-split finish
-constexpr int CVT_LDS_HEADER = CVT_WAVES * CVT_WAVE_CAP * 12 + 256;   // offset queue (u32) + norm-factor queue (f64) + counters, bytes
+constexpr int CVT_LDS_HEADER = CVT_WAVES * CVT_WAVE_CAP * 12 + 512;   // offset queue (u32) + norm-factor queue (f64) + counters + 32 reject words, bytes
 struct CvTileArgs {
     const uint32_t* sum;
     const uint64_t* sqsum;
@@ -384,9 +384,44 @@ struct CvTileArgs {
     uint32_t* det_count;
     uint32_t det_cap;
     unsigned long long* stage_entered;   // as CvArgs
+    // stage trees (mode 2): the survivors of the tree's linear prefix wait here for cv_tree_walk
+    struct CvTreeEntry* tq;
+    uint32_t* tq_count;
+    uint32_t tq_cap;
 };
-int launch_cv_tile_pass(const CvTileArgs& a, int mode /* 0: reject bits of stage 0, 1: the cascade on the visited windows */, bool count,
-                        int n_blocks, void* stream);
+// A window that passed the linear prefix of a stage tree inside a tile and walks the rest of the tree with global gathers.
+struct CvTreeEntry {
+    uint32_t off;        // byte offset of the window origin in the batch sum image
+    uint32_t word;       // its word in the reject / accept bitmaps (frame included)
+    uint32_t bit_slot;   // bit | scale slot << 8
+    uint32_t pad;
+    double   vnf;        // variance norm factor
+};
+int launch_cv_tile_pass(const CvTileArgs& a, int mode /* 0: reject bits of stage 0, 1: the cascade on the visited windows, 2: stage trees:
+                        the linear prefix on every grid window */, bool count, int n_blocks, void* stream);
+// Stage trees on tiles: the rest of the tree for the prefix's survivors (reject / accept bits), then — after skip_resolve — the
+// accepted windows the walk visits become detections (vj_cv_profile.hip).
+struct CvTreeArgs {
+    const uint32_t* sum;
+    const uint32_t* table;       // frame-stride CvNodeRec tables
+    const CvScaleDev* scales;
+    const StageDev* stages;
+    uint32_t n_order, prefix;    // sweep positions [prefix, n_order) are walked
+    uint32_t sum_bytes;          // n_frames * frame_elems * 4
+    const CvTreeEntry* tq;
+    const uint32_t* tq_count;
+    uint32_t tq_cap;
+    unsigned long long* reject;  // [n_frames][bits_frame_words]; visited bits after skip_resolve
+    unsigned long long* accept;
+    uint32_t bits_frame_words, n_frames;
+    const UnitDev* segs;         // one per window row of a tile scale: {scale slot, first word, words per row}
+    uint32_t n_segs;
+    CvDet* det;
+    uint32_t* det_count;
+    uint32_t det_cap;
+};
+int launch_cv_tree_walk(const CvTreeArgs& a, int n_blocks, void* stream);
+int launch_cv_tree_emit(const CvTreeArgs& a, int n_blocks, void* stream);
 int prepare_cv_tile_kernels();   // per device: raise the dynamic-LDS cap
 int launch_skip_resolve(const CascadeArgs& a, int n_blocks, void* stream);   // reject bits -> visited bits (vj_kernels.hip)
 

@@ -106,6 +106,8 @@ struct CvPlan {
     // LDS-tile path (vj_cv_tile.hip): tiles of one frame per LDS class, the rows of the scales that stay on
     // cv_profile_pass, and the per-frame reject / visited bitmap with one recurrence domain per window row
     uint32_t n_tile_scales = 0, n_rows_rest = 0, bits_frame_words = 0, n_bit_segs = 0;
+    uint32_t tree_prefix = 0;         // stage trees: stages of the linear prefix the tiles run (0: the cascade is linear)
+    uint64_t tile_windows = 0;        // grid windows of the tile scales, per frame
     uint32_t class_first[3] = {0, 0, 0}, class_lds[2] = {0, 0};
     DevBuf d_tiles, d_rows_rest, d_bit_segs;
     uint64_t last_used = 0;
@@ -212,6 +214,7 @@ struct vj_env {
     typedef std::tuple<uint64_t, int, int, int, int, uint64_t> CvPlanKey;   // cascade uid, W, H, min size, bits of the scale factor
     std::map<CvPlanKey, std::unique_ptr<vj::CvPlan>> cv_plans;
     vj::DevBuf d_cv_det, d_cv_counts;   // vj_detect_opencv: detection list and counters
+    vj::DevBuf d_cv_accept, d_cv_tq;    // ... stage trees on tiles: accept bitmap, the queue of the prefix's survivors
     uint64_t plan_tick = 0;
     int plan_cache_max = 48;      // plans kept per environment; the least recently used one is released beyond that
                                   // (a stream of ROI sizes — eyes inside faces of any size — would otherwise grow
