@@ -47,6 +47,17 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
     for (const auto& t : c->trees)
         if (t.n_nodes != 1) trees = true;
     for (const auto& nd : c->nodes) has_tilted |= nd.tilted != 0;
+    // two-node trees (frontalface_alt2): root + one node child — the shape the tile kernel's tree path knows
+    bool tree2 = trees;
+    for (const auto& t : c->trees) {
+        if (!tree2) break;
+        if (t.n_nodes != 2) { tree2 = false; break; }
+        const vj_node_desc& n0 = c->nodes[t.first_node];
+        const vj_node_desc& n1 = c->nodes[t.first_node + 1];
+        const int kids = (n0.left > 0) + (n0.right > 0);
+        if (kids != 1 || (n0.left > 0 ? n0.left : n0.right) != 1 || n1.left > 0 || n1.right > 0) tree2 = false;
+    }
+    pl->tree2 = tree2;
     pl->trees = trees;
     pl->is_tree = is_tree;
     pl->has_tilted = has_tilted;
@@ -93,6 +104,9 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
             ++tree_prefix;
     }
     pl->tree_prefix = tree_prefix;
+    // (a stage tree's row kernel evaluates the whole tree at every grid position and is far slower per window than the tiles'
+    // prefix: trees send every scale they can to tiles and leave the row kernel two workgroups per CU)
+    pl->row_blocks = is_tree ? e->cv_row_blocks_tree : e->cv_row_blocks;
     const size_t n_nodes = c->nodes.size();
     std::vector<CvScaleDev>& scales = pl->scales;
     scales.assign(hs.size(), CvScaleDev{});
@@ -194,7 +208,8 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
         // windows (tw divides 64, so a tile row never straddles a word of the reject / visited bitmap); its footprint is
         // the span of its window origins plus the furthest corner any feature or the equRect reaches.  Two LDS classes
         // like the clod profile's tiles: two workgroups per CU or one, next to one workgroup of cv_profile_pass.
-        if (e->cv_tiles && !trees && (!is_tree || tree_prefix != 0u) && !has_tilted && sd.end_x < 65536u && sd.end_y < 65536u) {
+        if (e->cv_tiles && (!trees || (tree2 && !is_tree)) && (!is_tree || tree_prefix != 0u) && !has_tilted && sd.end_x < 65536u &&
+            sd.end_y < 65536u) {
             uint32_t reach_x = (uint32_t)(ex + ew), reach_y = (uint32_t)(ex + eh);
             for (size_t n = 0; n < n_nodes; ++n) {
                 const CvNodeRec& r = recs[n];
@@ -208,7 +223,7 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
             static const uint32_t kTw[] = {64, 32, 16}, kTh[] = {32, 24, 16, 12, 8, 4};
             // LDS budget of a CU: the row kernel's workgroups (20 KiB each) stay resident next to two tile workgroups
             // of class 0 or one of class 1; a tile workgroup also owns CVT_LDS_HEADER bytes of queues
-            const uint32_t avail = 160u * 1024u - (uint32_t)e->cv_row_blocks * 20u * 1024u - 1024u;
+            const uint32_t avail = 160u * 1024u - (uint32_t)pl->row_blocks * 20u * 1024u - 1024u;
             const uint32_t class_bytes[2] = {avail / 2u - (uint32_t)CVT_LDS_HEADER, avail - (uint32_t)CVT_LDS_HEADER};
             uint32_t best_n = 0, b_tw = 0, b_th = 0, b_pitch = 0, b_rows = 0;
             int b_cls = -1;
@@ -222,7 +237,7 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
                         if (nwin > best_n) { best_n = nwin; b_tw = tw; b_th = th; b_pitch = pitch; b_rows = trows; }
                     }
                 // a class-0 tile must be worth two workgroups per CU; else try the larger class
-                if (best_n >= (uint32_t)(cls == 0 ? e->cv_tile_min_windows0 : e->cv_tile_min_windows))
+                if (best_n >= (uint32_t)(cls == 0 ? e->cv_tile_min_windows0 : is_tree ? e->cv_tile_min_windows_tree : e->cv_tile_min_windows))
                     b_cls = cls;
                 else
                     best_n = 0;
@@ -475,7 +490,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                     CvArgs b = a;
                     b.rows = (const UnitDev*)pl->d_rows_rest.p;
                     b.n_rows = pl->n_rows_rest;
-                    const int nb = std::max(1, e->n_cu * (two ? e->cv_row_blocks : 4));
+                    const int nb = std::max(1, e->n_cu * (two ? pl->row_blocks : 4));
                     b.total_waves = (uint32_t)nb * CV_WAVES_PER_BLOCK;
                     hrc = launch_cv_profile_pass(b, trees, false, true, nb, sB);
                 }
@@ -512,9 +527,9 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                     ta.n_tiles = n_cls;
                     ta.lds_bytes = pl->class_lds[cls];
                     ta.ticket = tickets + 8 * cls;
-                    const int per_cu = std::max(1, std::min(2, (int)((160u * 1024u - (uint32_t)e->cv_row_blocks * 20u * 1024u) / ta.lds_bytes)));
+                    const int per_cu = std::max(1, std::min(2, (int)((160u * 1024u - (uint32_t)pl->row_blocks * 20u * 1024u) / ta.lds_bytes)));
                     const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
-                    hrc = launch_cv_tile_pass(ta, 2, false, std::max(1, tb), e->stream);
+                    hrc = launch_cv_tile_pass(ta, 2, false, false, std::max(1, tb), e->stream);
                 }
                 CvTreeArgs w;
                 memset(&w, 0, sizeof(w));
@@ -569,7 +584,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                     CvArgs b = a;
                     b.rows = (const UnitDev*)pl->d_rows_rest.p;
                     b.n_rows = pl->n_rows_rest;
-                    const int nb = std::max(1, e->n_cu * (two ? e->cv_row_blocks : 4));
+                    const int nb = std::max(1, e->n_cu * (two ? pl->row_blocks : 4));
                     b.total_waves = (uint32_t)nb * CV_WAVES_PER_BLOCK;
                     hrc = launch_cv_profile_pass(b, trees, count, is_tree, nb, sB);
                 }
@@ -604,9 +619,9 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                         ta.n_tiles = n_cls;
                         ta.lds_bytes = pl->class_lds[cls];
                         ta.ticket = tickets + 8 * (mode * 2 + cls);
-                        const int per_cu = std::max(1, std::min(2, (int)((160u * 1024u - (uint32_t)e->cv_row_blocks * 20u * 1024u) / ta.lds_bytes)));
+                        const int per_cu = std::max(1, std::min(2, (int)((160u * 1024u - (uint32_t)pl->row_blocks * 20u * 1024u) / ta.lds_bytes)));
                         const int tb = (int)std::min<uint64_t>((uint64_t)n_cls * (uint64_t)nf, (uint64_t)e->n_cu * (uint64_t)per_cu);
-                        hrc = launch_cv_tile_pass(ta, mode, count, std::max(1, tb), e->stream);
+                        hrc = launch_cv_tile_pass(ta, mode, count, pl->tree2, std::max(1, tb), e->stream);
                     }
                     if (mode == 0 && !hrc) {   // reject bits -> visited bits, one recurrence domain per window row (skip_resolve)
                         CascadeArgs ra;

@@ -151,8 +151,54 @@ __device__ __forceinline__ void cvt_node_sum_pair(const char* img, const NodeRec
     sb = out[1];
 }
 
+// A two-node tree (root r0, its only node child r1 — every tree of frontalface_alt2) on one window: icvEvalHidHaarClassifier's
+// walk (tempcv.cpp:771-792: idx = sum < t ? left : right until idx <= 0; node sums are int * float products widened to
+// double, :783-788) with both nodes' gathers in flight.  Returns the leaf value; `code` names the leaf for an ordered replay
+// (bit 1: reached through the child, bit 0: right side).
+__device__ __forceinline__ double cvt_tree2_value(const char* img, const NodeRecDev& r0, const NodeRecDev& r1, uint32_t off, double vnf,
+                                                  uint32_t& code) {
+    double s0, s1;
+    cvt_node_sum_pair<false>(img, r0, r1, off, s0, s1);
+    const uint32_t flags0 = r0[15];
+    const bool left0 = s0 < (double)__uint_as_float(r0[12]) * vnf;
+    const bool left1 = s1 < (double)__uint_as_float(r1[12]) * vnf;
+    const bool to_child = left0 ? (flags0 & 1u) != 0u : (flags0 & 2u) != 0u;
+    const float leaf0 = left0 ? __uint_as_float(r0[13]) : __uint_as_float(r0[14]);
+    const float leaf1 = left1 ? __uint_as_float(r1[13]) : __uint_as_float(r1[14]);
+    code = to_child ? (left1 ? 2u : 3u) : (left0 ? 0u : 1u);
+    return (double)(to_child ? leaf1 : leaf0);
+}
+
+template <int NC>
+__device__ __forceinline__ void cvt_stage_sum_tree2_multi(const char* img, kptr<NodeRecDev> tab, uint32_t n_trees, const uint32_t (&off)[NC],
+                                                          const double (&vnf)[NC], double (&stage_sum)[NC]) {
+#pragma unroll
+    for (int c = 0; c < NC; ++c) stage_sum[c] = 0.0;
+    NodeRecDev r0 = tab[0], r1 = tab[1];
+    for (uint32_t t = 0; t < n_trees; ++t) {
+        const uint32_t tn = t + 1u < n_trees ? t + 1u : t;
+        const NodeRecDev n0 = tab[2u * tn], n1 = tab[2u * tn + 1u];
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            uint32_t code;
+            stage_sum[c] += cvt_tree2_value(img, r0, r1, off[c], vnf[c], code);
+        }
+        r0 = n0;
+        r1 = n1;
+    }
+}
+
+// One stage on NC chunks with the cascade's shape: stumps (with the stage's product type) or two-node trees.
+template <bool TREE2, int NC>
+__device__ __forceinline__ void cvt_stage_sum_any(const char* img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t f64,
+                                                  const uint32_t (&off)[NC], const double (&vnf)[NC], double (&sum)[NC]) {
+    if (TREE2) cvt_stage_sum_tree2_multi<NC>(img, tab, n_nodes >> 1, off, vnf, sum);
+    else cvt_stage_sum_mode<NC>(img, tab, n_nodes, f64, off, vnf, sum);
+}
+
 // Dense sweep of one stage over a wave's queue (qo / qv: tile-local byte offsets and norm factors), 4 / 2 / 1 chunks of 64
 // windows per stump; survivors are rewritten in place at their ballot ranks.  Returns the survivors.
+template <bool TREE2>
 __device__ __forceinline__ uint32_t cvt_sweep(const char* img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t f64, double thr,
                                               uint32_t* qo, double* qv, uint32_t n, uint32_t lane) {
     uint32_t m = 0, base = 0;
@@ -167,7 +213,7 @@ __device__ __forceinline__ uint32_t cvt_sweep(const char* img, kptr<NodeRecDev> 
             off[c] = raw[c] & CVT_OFF_MASK;   // (stage trees keep the window's index inside the tile above the offset)
             vnf[c] = qv[i < n ? i : 0u];
         }
-        cvt_stage_sum_mode<NC>(img, tab, n_nodes, f64, off, vnf, sum);
+        cvt_stage_sum_any<TREE2, NC>(img, tab, n_nodes, f64, off, vnf, sum);
         __builtin_amdgcn_wave_barrier();   // every entry of the group is in registers
 #pragma unroll
         for (int c = 0; c < NC; ++c) {
@@ -196,7 +242,7 @@ __device__ __forceinline__ uint32_t cvt_sweep(const char* img, kptr<NodeRecDev> 
 // taken from it when it clears the threshold by more than `delta`, an a-priori bound on the difference between any two
 // f64 summation orders of the stage's leaf values (4 n 2^-53 sum max|leaf|, from the host's f32 bound: sp_delta * 2^-28
 // keeps a factor 2 in hand); windows inside the band replay their verdict bits in stump order.  Bit-identical results.
-template <bool COUNT>
+template <bool COUNT, bool TREE2>
 __device__ __forceinline__ uint32_t cvt_wave_split(const CvTileArgs& a, const char* img, kptr<NodeRecDev> table, uint32_t* lds_off,
                                                    double* lds_vnf, uint32_t* lds_x, uint32_t* lds_cnt, uint32_t T, uint32_t pos0,
                                                    uint32_t lane, uint32_t wib) {
@@ -204,7 +250,9 @@ __device__ __forceinline__ uint32_t cvt_wave_split(const CvTileArgs& a, const ch
     constexpr uint32_t XW = 384u;   // dwords per producing wave: 64 f64 range sums, then 4 x 64 verdict words
     for (uint32_t s = pos0; s < a.n_stages && T != 0u; ++s) {
         if (COUNT && threadIdx.x == 0) atomicAdd(a.stage_entered + s, (unsigned long long)T);
-        const uint32_t n = stages[s].n_nodes, f64 = stages[s].cv_f64;
+        // items of a stage: stumps, or two-node trees (records 2t and 2t + 1; a 2-bit leaf code per tree instead of a verdict bit)
+        constexpr uint32_t PER_WORD = TREE2 ? 16u : 32u;
+        const uint32_t n = TREE2 ? stages[s].n_nodes >> 1 : stages[s].n_nodes, f64 = stages[s].cv_f64;
         const double thr_s = (double)stages[s].threshold;
         const double delta = (double)stages[s].sp_delta * 3.725290298461914e-09;   // 2^-28
         kptr<NodeRecDev> tab = table + stages[s].first_node;
@@ -212,7 +260,7 @@ __device__ __forceinline__ uint32_t cvt_wave_split(const CvTileArgs& a, const ch
         uint32_t K = (uint32_t)CVT_WAVES / c;
         uint32_t rs = (n + K - 1u) / K;
         rs = (rs + 1u) & ~1u;                      // even: pairs never straddle two ranges
-        if (rs > 128u || K == 1u) { K = 1u; rs = n; }
+        if (rs > 4u * PER_WORD || K == 1u) { K = 1u; rs = n; }
         const uint32_t chunk = wib % c, range = wib / c;   // uniform
         const uint32_t i = chunk * 64u + lane;
         const bool valid = i < T;
@@ -224,13 +272,28 @@ __device__ __forceinline__ uint32_t cvt_wave_split(const CvTileArgs& a, const ch
                 const uint32_t off1[1] = {off};
                 const double vnf1[1] = {vnf};
                 double sum1[1];
-                cvt_stage_sum_mode<1>(img, tab, n, f64, off1, vnf1, sum1);
+                cvt_stage_sum_any<TREE2, 1>(img, tab, stages[s].n_nodes, f64, off1, vnf1, sum1);
                 pass = valid && sum1[0] >= thr_s;
             } else {
                 const uint32_t j0 = min(range * rs, n), j1 = min(j0 + rs, n);
                 double psum = 0.0;
                 uint32_t* xw = lds_x + wib * XW;
-                for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += 32u, ++wd) {
+                for (uint32_t w0 = j0, wd = 0; TREE2 && w0 < j1; w0 += PER_WORD, ++wd) {
+                    const uint32_t m = min(PER_WORD, j1 - w0);
+                    uint32_t bw = 0u;
+                    NodeRecDev r0 = tab[2u * w0], r1 = tab[2u * w0 + 1u];
+                    for (uint32_t k = 0; k < m; ++k) {
+                        const uint32_t tn = min(w0 + k + 1u, j1 - 1u);
+                        const NodeRecDev n0 = tab[2u * tn], n1 = tab[2u * tn + 1u];
+                        uint32_t code;
+                        psum += cvt_tree2_value(img, r0, r1, off, vnf, code);
+                        bw |= code << (2u * k);
+                        r0 = n0;
+                        r1 = n1;
+                    }
+                    xw[128u + wd * 64u + lane] = bw;
+                }
+                for (uint32_t w0 = j0, wd = 0; !TREE2 && w0 < j1; w0 += 32u, ++wd) {
                     const uint32_t m = min(32u, j1 - w0);
                     uint32_t bw = 0u, k = 0;
                     NodeRecDev ra = tab[w0], rb = tab[min(w0 + 1u, j1 - 1u)];
@@ -274,12 +337,22 @@ __device__ __forceinline__ uint32_t cvt_wave_split(const CvTileArgs& a, const ch
                     for (uint32_t r = 0; r < K; ++r) {
                         const uint32_t j0 = min(r * rs, n), j1 = min(j0 + rs, n);
                         const uint32_t* xw = lds_x + (r * c + wib) * XW + 128u;
-                        for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += 32u, ++wd) {
-                            const uint32_t m = min(32u, j1 - w0);
+                        for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += PER_WORD, ++wd) {
+                            const uint32_t m = min(PER_WORD, j1 - w0);
                             const uint32_t bw = xw[wd * 64u + lane];
-                            kptr<uint32_t> lr = reinterpret_cast<kptr<uint32_t>>(tab + w0);
-                            for (uint32_t k = 0; k < m; ++k)
-                                sum += (double)((bw >> k) & 1u ? __uint_as_float(lr[k * 16u + 14u]) : __uint_as_float(lr[k * 16u + 13u]));
+                            if (TREE2) {
+                                kptr<uint32_t> lr = reinterpret_cast<kptr<uint32_t>>(tab + 2u * w0);
+                                for (uint32_t k = 0; k < m; ++k) {
+                                    const uint32_t code = (bw >> (2u * k)) & 3u;
+                                    const float l0 = __uint_as_float(lr[k * 32u + 13u]), r0 = __uint_as_float(lr[k * 32u + 14u]);
+                                    const float l1 = __uint_as_float(lr[k * 32u + 29u]), r1 = __uint_as_float(lr[k * 32u + 30u]);
+                                    sum += (double)(code & 2u ? (code & 1u ? r1 : l1) : (code & 1u ? r0 : l0));
+                                }
+                            } else {
+                                kptr<uint32_t> lr = reinterpret_cast<kptr<uint32_t>>(tab + w0);
+                                for (uint32_t k = 0; k < m; ++k)
+                                    sum += (double)((bw >> k) & 1u ? __uint_as_float(lr[k * 16u + 14u]) : __uint_as_float(lr[k * 16u + 13u]));
+                            }
                         }
                     }
                     if (!clear) pass = valid && sum >= thr_s;
@@ -312,7 +385,7 @@ __device__ __forceinline__ uint32_t cvt_wave_split(const CvTileArgs& a, const ch
 // every grid window): the tree's linear prefix — a.n_stages stages, 95 % of the rejects — on every grid window of the
 // tile; a window's reject bit starts set and is cleared when it survives the prefix; the survivors go to a global queue
 // for cv_tree_walk (vj_cv_profile.hip), which sets their reject or accept bit; skip_resolve and cv_tree_emit follow.
-template <int MODE, bool COUNT>
+template <int MODE, bool COUNT, bool TREE2>
 __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
     uint32_t* lds_off = lds_dyn;                                                              // [CVT_WAVES][CVT_WAVE_CAP]
@@ -445,7 +518,7 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
         if (MODE == 0) {
             // stage 0 on the wave's four rows at once; a window outside the grid or on the border is "not a reject"
             double sum[NCH];
-            cvt_stage_sum_mode<NCH>(img, table + stages[0].first_node, stages[0].n_nodes, stages[0].cv_f64, w_off, w_vnf, sum);
+            cvt_stage_sum_any<TREE2, NCH>(img, table + stages[0].first_node, stages[0].n_nodes, stages[0].cv_f64, w_off, w_vnf, sum);
             const double thr0 = (double)stages[0].threshold;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
@@ -517,7 +590,7 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
                     if (st >= a.ws_begin && total != 0u && total <= a.ws_max) {
                         // few windows left: the rest of the cascade with every stage's stumps split over the waves
                         uint32_t* lds_x = reinterpret_cast<uint32_t*>(lds_vnf + CVT_WS_MAX);
-                        const uint32_t left = cvt_wave_split<COUNT>(a, img, table, lds_off, lds_vnf, lds_x, lds_cnt, total, st, lane, wib);
+                        const uint32_t left = cvt_wave_split<COUNT, TREE2>(a, img, table, lds_off, lds_vnf, lds_x, lds_cnt, total, st, lane, wib);
                         if (wib == 0u && left != 0u) flush(lds_off, left);
                         finished = true;
                         break;
@@ -530,7 +603,7 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
                 }
                 if (n != 0u) {
                     if (COUNT && lane == 0) atomicAdd(a.stage_entered + st, (unsigned long long)n);
-                    n = cvt_sweep(img, table + stages[st].first_node, stages[st].n_nodes, stages[st].cv_f64, (double)stages[st].threshold, qo, qv,
+                    n = cvt_sweep<TREE2>(img, table + stages[st].first_node, stages[st].n_nodes, stages[st].cv_f64, (double)stages[st].threshold, qo, qv,
                                   n, lane);
                 }
             }
@@ -572,8 +645,10 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
 
 int prepare_cv_tile_kernels() {
     const int max_lds = 160 * 1024;
-    const void* fns[] = {(const void*)cv_tile_pass<0, false>, (const void*)cv_tile_pass<1, false>, (const void*)cv_tile_pass<1, true>,
-                         (const void*)cv_tile_pass<2, false>};
+    const void* fns[] = {(const void*)cv_tile_pass<0, false, false>, (const void*)cv_tile_pass<1, false, false>,
+                         (const void*)cv_tile_pass<1, true, false>,  (const void*)cv_tile_pass<2, false, false>,
+                         (const void*)cv_tile_pass<0, false, true>,  (const void*)cv_tile_pass<1, false, true>,
+                         (const void*)cv_tile_pass<1, true, true>};
     for (const void* f : fns) {
         const hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, max_lds);
         if (e != hipSuccess) return (int)e;
@@ -581,13 +656,20 @@ int prepare_cv_tile_kernels() {
     return 0;
 }
 
-int launch_cv_tile_pass(const CvTileArgs& a, int mode, bool count, int n_blocks, void* stream_) {
+int launch_cv_tile_pass(const CvTileArgs& a, int mode, bool count, bool tree2, int n_blocks, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     dim3 g(n_blocks), b(CVT_WAVES * 64);
-    if (mode == 0) hipLaunchKernelGGL((cv_tile_pass<0, false>), g, b, a.lds_bytes, stream, a);
-    else if (mode == 2) hipLaunchKernelGGL((cv_tile_pass<2, false>), g, b, a.lds_bytes, stream, a);
-    else if (count) hipLaunchKernelGGL((cv_tile_pass<1, true>), g, b, a.lds_bytes, stream, a);
-    else hipLaunchKernelGGL((cv_tile_pass<1, false>), g, b, a.lds_bytes, stream, a);
+    if (tree2) {
+        if (mode == 0) hipLaunchKernelGGL((cv_tile_pass<0, false, true>), g, b, a.lds_bytes, stream, a);
+        else if (mode == 2) return (int)hipErrorInvalidValue;      // stage trees on tiles are stump cascades
+        else if (count) hipLaunchKernelGGL((cv_tile_pass<1, true, true>), g, b, a.lds_bytes, stream, a);
+        else hipLaunchKernelGGL((cv_tile_pass<1, false, true>), g, b, a.lds_bytes, stream, a);
+    } else {
+        if (mode == 0) hipLaunchKernelGGL((cv_tile_pass<0, false, false>), g, b, a.lds_bytes, stream, a);
+        else if (mode == 2) hipLaunchKernelGGL((cv_tile_pass<2, false, false>), g, b, a.lds_bytes, stream, a);
+        else if (count) hipLaunchKernelGGL((cv_tile_pass<1, true, false>), g, b, a.lds_bytes, stream, a);
+        else hipLaunchKernelGGL((cv_tile_pass<1, false, false>), g, b, a.lds_bytes, stream, a);
+    }
     return (int)hipGetLastError();
 }
 

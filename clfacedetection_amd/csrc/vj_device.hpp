@@ -398,7 +398,7 @@ struct CvTreeEntry {
     double   vnf;        // variance norm factor
 };
 int launch_cv_tile_pass(const CvTileArgs& a, int mode /* 0: reject bits of stage 0, 1: the cascade on the visited windows, 2: stage trees:
-                        the linear prefix on every grid window */, bool count, int n_blocks, void* stream);
+                        the linear prefix on every grid window */, bool count, bool tree2 /* every tree: a root and one node child */, int n_blocks, void* stream);
 // Stage trees on tiles: the rest of the tree for the prefix's survivors (reject / accept bits), then — after skip_resolve — the
 // accepted windows the walk visits become detections (vj_cv_profile.hip).
 struct CvTreeArgs {

@@ -1769,13 +1769,16 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         return VJ_OK;
     }
     if (strcmp(key, "cv_tiles") == 0 || strcmp(key, "cv_tile_ws_max") == 0 || strcmp(key, "cv_tile_min_windows") == 0 ||
-        strcmp(key, "cv_row_blocks") == 0 || strcmp(key, "cv_tile_min_windows0") == 0) {
+        strcmp(key, "cv_row_blocks") == 0 || strcmp(key, "cv_tile_min_windows0") == 0 || strcmp(key, "cv_row_blocks_tree") == 0 ||
+        strcmp(key, "cv_tile_min_windows_tree") == 0) {
         // OpenCV profile: 0 = every scale on cv_profile_pass; the finish threshold; the smallest tile worth staging
         const int v = atoi(value);
         if (strcmp(key, "cv_tiles") == 0) e->cv_tiles = v != 0;
         else if (strcmp(key, "cv_tile_ws_max") == 0) e->cv_tile_ws_max = std::max(0, std::min(v, (int)CVT_WS_MAX));
         else if (strcmp(key, "cv_row_blocks") == 0) e->cv_row_blocks = std::max(1, std::min(v, 4));
         else if (strcmp(key, "cv_tile_min_windows0") == 0) e->cv_tile_min_windows0 = std::max(64, v);
+        else if (strcmp(key, "cv_row_blocks_tree") == 0) e->cv_row_blocks_tree = std::max(1, std::min(v, 4));
+        else if (strcmp(key, "cv_tile_min_windows_tree") == 0) e->cv_tile_min_windows_tree = std::max(64, v);
         else e->cv_tile_min_windows = std::max(64, v);
         HIP_TRY(hipStreamSynchronize(e->stream));
         for (auto& kv : e->cv_plans) kv.second->release_device();

@@ -101,11 +101,12 @@ struct CvPlan {
     std::vector<CvScaleDev> scales;   // host copy (window sizes and scale indices of the result)
     StageProgram prog;
     uint32_t n_stages = 0, n_order = 0, n_rows = 0;
-    bool trees = false, is_tree = false, has_tilted = false;
+    bool trees = false, is_tree = false, has_tilted = false, tree2 = false;
     DevBuf d_table, d_scales, d_stages, d_rows;
     // LDS-tile path (vj_cv_tile.hip): tiles of one frame per LDS class, the rows of the scales that stay on
     // cv_profile_pass, and the per-frame reject / visited bitmap with one recurrence domain per window row
     uint32_t n_tile_scales = 0, n_rows_rest = 0, bits_frame_words = 0, n_bit_segs = 0;
+    int row_blocks = 1;               // workgroups per CU of cv_profile_pass next to the tiles
     uint32_t tree_prefix = 0;         // stage trees: stages of the linear prefix the tiles run (0: the cascade is linear)
     uint64_t tile_windows = 0;        // grid windows of the tile scales, per frame
     uint32_t class_first[3] = {0, 0, 0}, class_lds[2] = {0, 0};
@@ -245,6 +246,7 @@ struct vj_env {
     bool cv_tiles = true;         // OpenCV profile: small scales of stump cascades on LDS tiles (vj_cv_tile.hip)
     int cv_tile_ws_max = 512;     // ... windows a tile carries into its wave-split finish
     int cv_row_blocks = 3;        // ... workgroups per CU of cv_profile_pass while it runs next to the tiles (their LDS budget shrinks with it)
+    int cv_row_blocks_tree = 2, cv_tile_min_windows_tree = 512;   // ... the same two for stage trees (swept: profiles/r03_cv_sweeps.log)
     int cv_tile_min_windows0 = 2048;   // ... the same for the class with two tile workgroups per CU
     int cv_tile_min_windows = 1536;   // ... a scale goes to tiles when a tile of at least this many windows fits the LDS
     bool rois_on_device = true;   // vj_detect_rois: one region pass on the frames' integral images (0: one vj_detect per region size)

@@ -210,6 +210,8 @@ def test_plan_cache_of_the_profile(env, oracle, cascades):
     ("frontalface_default", "blocks", 34, 480, 640, 2),       # 24 x 24 window, 25 stages
     ("eye", "noise", 35, 200, 333, 4),                        # window rows that are not a multiple of the tile width
     ("frontalface_alt", "white", 0, 200, 500, 1),             # flat: every window rejects at stage 0 (variance 0), long skip runs
+    ("frontalface_alt2", "faces", 39, 540, 960, 2),            # two-node trees: both nodes' gathers in flight, 2-bit leaf codes in the finish
+    ("frontalface_alt2", "noise", 40, 300, 420, 3),
     ("frontalface_alt_tree", "faces", 36, 540, 960, 2),       # stage tree: prefix on tiles, cv_tree_walk, skip_resolve, cv_tree_emit
     ("frontalface_alt_tree", "noise", 37, 300, 420, 3),       # (the counted call of a stage tree walks the rows: the plain one is the tile path)
     ("frontalface_alt_tree", "smooth", 38, 400, 700, 1),
