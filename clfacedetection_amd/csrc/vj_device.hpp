@@ -41,7 +41,7 @@ struct ScaleDev {
     uint32_t skip_wpr;     // ... words per window row (VJ_FLAG_SKIP_ROW); 0: one flattened bit list (VJ_FLAG_SKIP_LIST)
     float    scale_f;      // s_k itself, and the scaled window: what a region of interest needs to lay out its own grid
     uint32_t win_w, win_h; // ... (setupScale, clod.cpp:371-415, evaluated on the device per region: roi_plan_units)
-    uint32_t pad[1];
+    uint32_t pos_base;     // != 0: window positions of this scale come from CascadeArgs::pos_tab[pos_base + index] (VJ_FLAG_GRID_F64)
 };
 static_assert(sizeof(ScaleDev) == 128, "ScaleDev is 128 bytes");
 
@@ -196,7 +196,8 @@ struct CascadeArgs {
     uint32_t  sp_tail_max;              // global-gather sweeps: at most this many windows left in a wave -> stump-parallel tail (0: off; <= 48)
     uint32_t  max_stage_nodes;          // nodes of the cascade's largest stage
     uint32_t  gather_pairs;             // global-gather sweeps evaluate two stumps per step: 0 never, 1 when the wave holds one chunk, 2 always
-    uint32_t  pos_mode;                 // window_pos(): bit 0 = round half away from zero (clod.cpp:1416, :1034) instead of lrint (:514, :941); bit 1 = f64 product (block variant, :862)
+    uint32_t  pos_mode;                 // window_pos(): bit 0 = round half away from zero (clod.cpp:1416) instead of lrint (:514); bit 1: the block variant's f64 grid (ScaleDev::pos_base tables)
+    const uint32_t* pos_tab;            // positions of the f64 grids (VJ_FLAG_GRID_F64), per scale from ScaleDev::pos_base; entry 0 is unused
     const UnitDev* skip_units;          // one per bitmap word of a frame: {scale, first window (flattened index, or ix0 | iy << 16), valid bits, word}
     uint32_t  n_skip_units;
     const UnitDev* skip_segs;           // one per recurrence domain (a window row, or a scale's whole list): {scale, first word, words, -}

@@ -140,6 +140,7 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     }
     const uint32_t tile_header_bytes = TILE_LDS_HEADER + pl->sp_pad * 4u;
     std::vector<NodeRec> table;
+    std::vector<uint32_t> pos_tab;
     for (const vj_scale_info& si : pl->scales_all) {
         if (!si.accepted || si.nx <= 0 || si.ny <= 0) continue;
         if ((p.scale_mask[0] | p.scale_mask[1]) != 0) {  // scale subset (multi-GPU sharding of one frame)
@@ -182,6 +183,16 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         pl->max_reach_elems = std::max(pl->max_reach_elems, reach);
         pl->windows_per_frame += sd.nwin;
         sd.ny = (uint32_t)si.ny;
+        if (pl->pos_mode & 2u) {
+            // the block variant's positions, index by index, with the reference's own expressions: lrint(index * step) in
+            // its row loop (clod.cpp:941-942), round(index * step) in its per-stage lists (:1034), `step` a double (:862)
+            if (pos_tab.empty()) pos_tab.push_back(0u);   // (base 0 means "no table")
+            sd.pos_base = (uint32_t)pos_tab.size();
+            const double stepd = std::max(2.0, (double)si.scale);
+            const int n_pos = std::max(si.nx, si.ny) + 1;
+            for (int i = 0; i < n_pos; ++i)
+                pos_tab.push_back((pl->pos_mode & 1u) ? (uint32_t)std::round((double)i * stepd) : (uint32_t)std::lrint((double)i * stepd));
+        }
 
         // LDS-tile path: does a 64 x (TILE_WAVES * rw) window tile's footprint fit the budget?
         uint32_t reach_x = (uint32_t)(si.equ_x + si.equ_w), reach_y = (uint32_t)(si.equ_y + si.equ_h);
@@ -508,6 +519,10 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     if ((rc = pl->d_stages.ensure(pl->stages.size() * sizeof(StageDev)))) return rc;
     if ((rc = pl->d_units.ensure(std::max<size_t>(pl->units.size(), 1) * sizeof(UnitDev)))) return rc;
     if ((rc = pl->d_tile_units.ensure(std::max<size_t>(pl->tile_units.size(), 1) * sizeof(UnitDev)))) return rc;
+    if (!pos_tab.empty()) {
+        if ((rc = pl->d_pos_tab.ensure(pos_tab.size() * sizeof(uint32_t)))) return rc;
+        HIP_TRY(hipMemcpy(pl->d_pos_tab.p, pos_tab.data(), pos_tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
     if ((rc = pl->d_sp_blocks.ensure(std::max<size_t>(sp_blocks.size(), 1) * sizeof(SpBlock)))) return rc;
     if (!sp_blocks.empty())
         HIP_TRY(hipMemcpy(pl->d_sp_blocks.p, sp_blocks.data(), sp_blocks.size() * sizeof(SpBlock), hipMemcpyHostToDevice));
@@ -998,6 +1013,7 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
         ca.tile_ws_min = pl->sp_pad != 0u ? (uint32_t)e->tile_ws_min : 0u;   // no stump-parallel tables: wave-split to the end
         ca.tile_ws_max = (uint32_t)std::min(e->tile_ws_max, (int)TILE_WS_MAX_WINDOWS);
         ca.pos_mode = pl->pos_mode;
+        ca.pos_tab = (const uint32_t*)pl->d_pos_tab.p;
         ca.gather_pairs = e->pairs_for(nf);
         ca.sp_tail_max = (uint32_t)std::max(0, std::min(e->sp_tail_max, 48));
         ca.max_stage_nodes = pl->max_stage_nodes;

@@ -83,7 +83,7 @@ struct Plan {
     uint32_t max_stage_nodes = 0;
     StageProgram prog;
     // device copies
-    DevBuf d_table, d_scales, d_stages, d_units, d_tile_units, d_sp_blocks, d_skip_units, d_skip_segs;
+    DevBuf d_table, d_scales, d_stages, d_units, d_tile_units, d_sp_blocks, d_skip_units, d_skip_segs, d_pos_tab;
     // P2 skip modes (VJ_FLAG_SKIP_LIST / VJ_FLAG_SKIP_ROW): bitmap geometry and work lists of the two bitmap kernels
     uint32_t skip_mode = 0, pos_mode = 0, skip_frame_words = 0, n_skip_units = 0, n_skip_segs = 0;
     uint32_t n_sp_blocks = 0;
@@ -91,7 +91,7 @@ struct Plan {
     uint64_t last_used = 0;   // vj_env::plan_tick of the last call that used this plan (LRU eviction)
     float tile_split = 0.0f;  // the chain balance this plan was built for (vj_env::split_for)
     void release_device() {
-        for (DevBuf* b : {&d_table, &d_scales, &d_stages, &d_units, &d_tile_units, &d_sp_blocks, &d_skip_units, &d_skip_segs}) b->release();
+        for (DevBuf* b : {&d_table, &d_scales, &d_stages, &d_units, &d_tile_units, &d_sp_blocks, &d_skip_units, &d_skip_segs, &d_pos_tab}) b->release();
     }
 };
 

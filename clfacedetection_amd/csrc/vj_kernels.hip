@@ -316,14 +316,13 @@ int launch_integral(const IntegralArgs& a, void* stream_) {
 // OpenCL path) or the plain CPU loop's round(i * step) (clod.cpp:1416, half away from zero; VJ_FLAG_SKIP_ROW).  The
 // block variant keeps `step` as a double (clod.cpp:862), so its product is the f64 one — exact, where the f32 product
 // is rounded to 24 bits first and may land on the other side of a half (VJ_FLAG_GRID_F64; lrint at :941-942, round()
-// at :1034).  pos_mode is wave-uniform: bit 0 = half away from zero, bit 1 = f64 product.
-__device__ __forceinline__ uint32_t window_pos(uint32_t i, float step, uint32_t pos_mode) {
-    if (pos_mode & 2u) {
-        const double v = (double)i * (double)step;
-        return (pos_mode & 1u) ? (uint32_t)round(v) : (uint32_t)__double2int_rn(v);
-    }
+// at :1034): those positions come from a per-scale table the host fills with the reference's own f64 expression
+// (pos_base != 0; f64 arithmetic here cost the tile kernel a register allocation granule and the gather chain next to
+// it 2 ms of config 4, profiles/r03_notes.md #9).  pos_mode / pos_base are wave-uniform.
+__device__ __forceinline__ uint32_t window_pos(const CascadeArgs& a, uint32_t pos_base, uint32_t i, float step) {
+    if (pos_base != 0u) return a.pos_tab[pos_base + i];
     const float v = (float)i * step;
-    return (pos_mode & 1u) ? (uint32_t)roundf(v) : (uint32_t)__float2int_rn(v);
+    return (a.pos_mode & 1u) ? (uint32_t)roundf(v) : (uint32_t)__float2int_rn(v);
 }
 
 // P2 skip modes: is grid window (ix, iy) of this scale one the reference's sequential loop visits?
@@ -945,6 +944,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
             const uint32_t first = units[r].first;
             const uint32_t count = units[r].count;
             const float step = scales[slot].step;
+            const uint32_t pos_base = scales[slot].pos_base;
             const uint32_t nx = scales[slot].nx;
             const uint32_t e_lt = scales[slot].e_lt, e_dw = scales[slot].e_dw, e_dh = scales[slot].e_dh;
             const float area = scales[slot].area;
@@ -973,8 +973,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
                     valid = window_visited(a, frame, scales[slot].skip_base, scales[slot].skip_wpr, nx, ix, iy);
                 QEntry en{0u, 0.0f};
                 if (valid) {
-                    const uint32_t x = window_pos(ix, step, a.pos_mode);
-                    const uint32_t y = window_pos(iy, step, a.pos_mode);
+                    const uint32_t x = window_pos(a, pos_base, ix, step);
+                    const uint32_t y = window_pos(a, pos_base, iy, step);
                     const uint32_t e = y * a.stride + x;
                     en.var = window_variance(sum_f, sq_f, e, e_lt, e_dw, e_dh, area, a.signed_mean != 0u);
                     en.off = frame_bytes + e * 4u;
@@ -1060,8 +1060,17 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
             // of any: the waves of an XCD then work on about one frame's sum image at a time (8 MB) instead of sweeping
             // the part's whole frame group (66 MB for 64 x 1080p) once per scale.  q_slices = 1: scale by scale.
             uint32_t slot = a.n_scales, c = t;
-            if (t < part_chunks) {
-                const uint32_t J = max(a.q_slices, 1u);
+            if (t < part_chunks && a.q_slices <= 1u) {
+                // (the plain walk: no divisions — a thin pass draws thousands of tickets per wave, and a scalar integer
+                // division is a long instruction sequence: with the sliced walk for J = 1 the chains of a stage tree took
+                // 2.9 ms instead of 0.43)
+                for (slot = 0; slot < a.n_scales; ++slot) {
+                    const uint32_t n_chunks = (counts[slot * Q_PARTS + part] + chunk - 1u) / chunk;
+                    if (c < n_chunks) break;
+                    c -= n_chunks;
+                }
+            } else if (t < part_chunks) {
+                const uint32_t J = a.q_slices;
                 bool found = false;
                 for (uint32_t j = 0; j < J && !found; ++j)
                     for (slot = 0; slot < a.n_scales; ++slot) {
@@ -1129,6 +1138,7 @@ __global__ __launch_bounds__(256) void skip_fail_bits(CascadeArgs a) {
         const uint32_t slot = units[r].scale, first = units[r].first, count = units[r].count, word = units[r].bw;
         const uint32_t nx = scales[slot].nx;
         const float step = scales[slot].step;
+        const uint32_t pos_base = scales[slot].pos_base;
         uint32_t ix, iy;
         if (scales[slot].skip_wpr != 0u) {
             ix = (first & 0xffffu) + lane;
@@ -1143,7 +1153,7 @@ __global__ __launch_bounds__(256) void skip_fail_bits(CascadeArgs a) {
             const size_t frame_off = (size_t)frame * a.frame_elems;
             const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
             const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
-            const uint32_t x = window_pos(ix, step, a.pos_mode), y = window_pos(iy, step, a.pos_mode);
+            const uint32_t x = window_pos(a, pos_base, ix, step), y = window_pos(a, pos_base, iy, step);
             const uint32_t e = y * a.stride + x;
             const float var = window_variance(sum_f, sq_f, e, scales[slot].e_lt, scales[slot].e_dw, scales[slot].e_dh, scales[slot].area,
                                               a.signed_mean != 0u);
@@ -1874,6 +1884,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         const uint32_t slot = units[r].scale;
         const uint32_t ix0 = units[r].first & 0xffffu, iy0 = units[r].first >> 16;
         const float step = scales[slot].step;
+        const uint32_t pos_base = scales[slot].pos_base;
         const uint32_t nx = scales[slot].nx, ny = scales[slot].ny;
         const uint32_t tw = scales[slot].tile_tw, th = scales[slot].tile_th;
         const uint32_t pitch = STAGED ? scales[slot].tile_pitch : 0u, rows = STAGED ? scales[slot].tile_rows : 0u;
@@ -1882,8 +1893,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
         const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
         // tile origin in the image: the first window's origin (same expression as below)
-        const uint32_t x0 = __builtin_amdgcn_readfirstlane(window_pos(ix0, step, a.pos_mode));
-        const uint32_t y0 = __builtin_amdgcn_readfirstlane(window_pos(iy0, step, a.pos_mode));
+        const uint32_t x0 = __builtin_amdgcn_readfirstlane(window_pos(a, pos_base, ix0, step));
+        const uint32_t y0 = __builtin_amdgcn_readfirstlane(window_pos(a, pos_base, iy0, step));
 
         __syncthreads();  // the previous tile's gathers are finished
         STAMP(0);
@@ -1954,8 +1965,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
             w_lo4[k] = 0u;
             w_q[k] = 0ull;
             if (w_valid[k]) {
-                const uint32_t x = window_pos(ix, step, a.pos_mode);
-                const uint32_t y = window_pos(iy, step, a.pos_mode);
+                const uint32_t x = window_pos(a, pos_base, ix, step);
+                const uint32_t y = window_pos(a, pos_base, iy, step);
                 // byte offset inside the tile (de-interleaved rows: window origins are even columns)
                 const uint32_t e = y * a.stride + x;
                 // unstaged blocks: byte offset in the batch sum image, as in cascade_pass
