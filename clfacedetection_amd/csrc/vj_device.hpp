@@ -101,6 +101,12 @@ struct RoiDet {
     uint32_t slot;
     uint32_t roi;
 };
+struct RoiTile {           // one LDS tile inside a region (cascade_tile_roi_pass)
+    uint32_t roi;
+    uint32_t slot;
+    uint32_t first;        // ix0 | iy0 << 16 in the region's own grid of this scale
+    uint32_t nxy;          // the region's grid: nx | ny << 16
+};
 
 // One block of <= 64 consecutive nodes of a stage (stump-parallel finish of the tile kernel).
 struct SpBlock {
@@ -253,9 +259,15 @@ struct RoiArgs {
     RoiDet* det;
     uint32_t* det_count;
     uint32_t det_cap;
+    // cascade_tile_roi_pass: (region, scale) grids of at least tile_min_windows windows on two-per-CU tile scales (null: none)
+    RoiTile* tiles;
+    uint32_t* n_tiles;
+    uint32_t max_tiles;
+    uint32_t tile_min_windows;
+    uint32_t tile_blocks;        // workgroups of the launch
 };
 int launch_roi_chain(const RoiArgs& r, const CascadeArgs& a, bool from_dets, bool trees, bool count, bool general /* stage tree */,
-                     int n_blocks, void* stream);
+                     int n_blocks, void* stream, void* stream2 /* may be null */, void* fork_ev, void* join_ev);
 
 // Grouping of a first cascade's raw candidates on the device (vj_detect_chain with min_neighbors != 0): the grouped
 // rectangles become the region list of the second cascade without a host round trip (vj_group_dev.hip).

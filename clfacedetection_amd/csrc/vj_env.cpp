@@ -1479,6 +1479,35 @@ static void fill_region_args(vj_env* e, Lane* L, Plan* pl2, const vj_cascade* se
     ca.sp_tail_max = (uint32_t)std::max(0, std::min(e->sp_tail_max, 48));
     ca.max_stage_nodes = pl2->max_stage_nodes;
     ca.stage_entered = (unsigned long long*)(roi_counts + 8);
+    // Regions with large grids at the small scales (many raw candidates, big faces) run those grids on the tile kernel
+    // (cascade_tile_roi_pass: tiles of the second cascade's two-per-CU tile scales, laid inside the region): stump cascades
+    // whose plan has such tiles.  The caller sizes e->d_roi_tiles and zeroes the eight ticket counters.
+    if (e->roi_tile_min_windows > 0 && !pl2->general && !pl2->trees && pl2->sp_pad != 0u && pl2->class_first[1] > pl2->class_first[0] &&
+        e->roi_tile_cap != 0u) {
+        ra.tiles = (RoiTile*)e->d_roi_tiles.p;
+        ra.n_tiles = roi_counts + 6;
+        ra.max_tiles = e->roi_tile_cap;
+        ra.tile_min_windows = (uint32_t)e->roi_tile_min_windows;
+        ca.tile_lds_bytes = pl2->class_lds[0];
+        const int per_cu = std::max(1, std::min(32 / TILE_WAVES, (int)(160u * 1024u / ca.tile_lds_bytes)));
+        ra.tile_blocks = (uint32_t)std::max(1, e->n_cu * per_cu);
+        ca.tile_ticket = (uint32_t*)L->d_counts.p + (CountsLayout::q_counts - 40u);
+        ca.n_pass = 1;                       // the whole cascade inside the tile: survivors are detections
+        ca.pass_begin[0] = 0;
+        ca.pass_begin[1] = (uint32_t)pl2->stages.size();
+        ca.tile_end = (uint32_t)pl2->stages.size();
+        ca.tile_min_lanes = 0;
+        ca.tile_repack_mask = e->tile_repack_mask;
+        ca.tile_sp_begin = (uint32_t)e->tile_sp_begin;
+        ca.tile_sp_pad = pl2->sp_pad;
+        ca.sp_blocks = (const SpBlock*)pl2->d_sp_blocks.p;
+        ca.n_sp_blocks = pl2->n_sp_blocks;
+        ca.tile_sp_max = (uint32_t)std::min(e->tile_sp_max, (int)TILE_SP_MAX_WINDOWS);
+        ca.xcd_affinity = (uint32_t)e->xcd_affinity;
+        ca.tile_finish = (uint32_t)e->tile_finish;
+        ca.tile_ws_min = (uint32_t)e->tile_ws_min;
+        ca.tile_ws_max = (uint32_t)std::min(e->tile_ws_max, (int)TILE_WS_MAX_WINDOWS);
+    }
 }
 
 // vj_detect_rois on frames of one size with a linear cascade: one integral per frame and ONE region pass for regions of
@@ -1526,6 +1555,9 @@ static int detect_rois_on_device(vj_env* e, const vj_cascade* c, const vj_image*
         for (int attempt = 0; attempt < 6 && !ok; ++attempt) {
             if ((rc = e->d_roi_units.ensure((size_t)e->roi_unit_cap * sizeof(RoiUnit)))) return rc;
             if ((rc = e->d_roi_det.ensure((size_t)e->roi_det_cap * sizeof(RoiDet)))) return rc;
+            if (e->roi_tile_cap == 0) e->roi_tile_cap = 1u << 16;
+            if ((rc = e->d_roi_tiles.ensure((size_t)e->roi_tile_cap * sizeof(RoiTile)))) return rc;
+            HIP_TRY(hipMemsetAsync((uint32_t*)L->d_counts.p + (CountsLayout::q_counts - 40u), 0, 8 * 4, e->stream));   // tile tickets of the region pass
             uint32_t* roi_counts = (uint32_t*)L->d_counts.p + CountsLayout::roi_off_u32;
             HIP_TRY(hipMemsetAsync(roi_counts, 0, (8 + (size_t)VJ_MAX_STAGES * 2) * 4, e->stream));
             HIP_TRY(hipMemcpyAsync(roi_counts, &n_reg, 4, hipMemcpyHostToDevice, e->stream));
@@ -1533,7 +1565,8 @@ static int detect_rois_on_device(vj_env* e, const vj_cascade* c, const vj_image*
             CascadeArgs ca;
             fill_region_args(e, L, pl2, c, *p, W, H, nf, n_reg, &ra, &ca);
             HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], e->stream));
-            const int hrc = launch_roi_chain(ra, ca, false, pl2->trees, count2, pl2->general, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
+            const int hrc = launch_roi_chain(ra, ca, false, pl2->trees, count2, pl2->general, std::max(1, e->n_cu * e->blocks_per_cu), e->stream,
+                                             e->concurrent ? e->stream2 : nullptr, e->fork_ev, e->join_ev);
             if (hrc) {
                 set_error("region pass launch failed: %s", hipGetErrorString((hipError_t)hrc));
                 return VJ_ERR_HIP;
@@ -1550,9 +1583,11 @@ static int detect_rois_on_device(vj_env* e, const vj_cascade* c, const vj_image*
                 set_error("internal error: %u regions outside their frames", hc[CountsLayout::roi_off_u32 + 2]);
                 return VJ_ERR_HIP;
             }
-            if (n_units > e->roi_unit_cap || n_det2 > e->roi_det_cap) {
+            const uint32_t n_tiles2 = hc[CountsLayout::roi_off_u32 + 6];
+            if (n_units > e->roi_unit_cap || n_det2 > e->roi_det_cap || n_tiles2 > e->roi_tile_cap) {
                 while (e->roi_unit_cap < n_units) e->roi_unit_cap *= 2;
                 while (e->roi_det_cap < n_det2) e->roi_det_cap *= 2;
+                while (e->roi_tile_cap < n_tiles2) e->roi_tile_cap *= 2;
                 continue;
             }
             HIP_TRY(hipEventElapsedTime(&ms_roi, L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], L->launch_ev[2 * VJ_MAX_LAUNCHES - 1]));
@@ -1778,6 +1813,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "tree_split_queues") == 0) {
         e->tree_split_queues = atoi(value) != 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "roi_tiles") == 0) {   // region pass: smallest (region, scale) grid that runs on LDS tiles (0: none)
+        e->roi_tile_min_windows = std::max(0, atoi(value));
         return VJ_OK;
     }
     if (strcmp(key, "rois_on_device") == 0) {
@@ -2328,7 +2367,9 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
             }
             if ((rc = e->d_roi_units.ensure((size_t)e->roi_unit_cap * sizeof(RoiUnit)))) return rc;
             if ((rc = e->d_roi_det.ensure((size_t)e->roi_det_cap * sizeof(RoiDet)))) return rc;
-            uint32_t* roi_counts = (uint32_t*)L->d_counts.p + CountsLayout::roi_off_u32;   // zeroed with the block by enqueue_cascade
+            if (e->roi_tile_cap == 0) e->roi_tile_cap = 1u << 16;
+            if ((rc = e->d_roi_tiles.ensure((size_t)e->roi_tile_cap * sizeof(RoiTile)))) return rc;
+            uint32_t* roi_counts = (uint32_t*)L->d_counts.p + CountsLayout::roi_off_u32;   // zeroed with the block by enqueue_cascade (the tile tickets too)
             RoiArgs ra;
             CascadeArgs ca;
             fill_region_args(e, L, pl2, second, *p_second, W, H, nf, L->det_cap, &ra, &ca);
@@ -2346,7 +2387,8 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
                 }
                 HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 5, ga.overflow, 4, hipMemcpyDeviceToHost, e->stream));
             }
-            const int hrc = launch_roi_chain(ra, ca, !grouped, pl2->trees, count2, pl2->general, std::max(1, e->n_cu * e->blocks_per_cu), e->stream);
+            const int hrc = launch_roi_chain(ra, ca, !grouped, pl2->trees, count2, pl2->general, std::max(1, e->n_cu * e->blocks_per_cu), e->stream,
+                                             e->concurrent ? e->stream2 : nullptr, e->fork_ev, e->join_ev);
             if (hrc) {
                 set_error("region pass launch failed: %s", hipGetErrorString((hipError_t)hrc));
                 return VJ_ERR_HIP;
@@ -2354,6 +2396,7 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
             HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 1], e->stream));
             // the region counters join the block enqueue_cascade already copies; copy them again now that they are final
             HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32, roi_counts, 5 * 4, hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 6, roi_counts + 6, 4, hipMemcpyDeviceToHost, e->stream));   // region tiles
             HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 8, roi_counts + 8, (size_t)VJ_MAX_STAGES * 2 * 4,
                                    hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipEventRecord(L->done, e->stream));
@@ -2386,9 +2429,11 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
                 }
                 return vj_detect_rois(e, second, frames, n_frames, rois.data(), (int)rois.size(), p_second, out_second);
             }
-            if (n_units > e->roi_unit_cap || n_det2 > e->roi_det_cap) {
+            const uint32_t n_tiles2 = hc[CountsLayout::roi_off_u32 + 6];
+            if (n_units > e->roi_unit_cap || n_det2 > e->roi_det_cap || n_tiles2 > e->roi_tile_cap) {
                 while (e->roi_unit_cap < n_units) e->roi_unit_cap *= 2;
                 while (e->roi_det_cap < n_det2) e->roi_det_cap *= 2;
+                while (e->roi_tile_cap < n_tiles2) e->roi_tile_cap *= 2;
                 continue;
             }
             HIP_TRY(hipEventElapsedTime(&ms_roi, L->launch_ev[2 * VJ_MAX_LAUNCHES - 2], L->launch_ev[2 * VJ_MAX_LAUNCHES - 1]));

@@ -196,7 +196,9 @@ struct vj_env {
     vj::DevBuf d_q[vj::MAX_PASSES];   // d_q[p]: windows waiting to enter pass p (p >= 1)
     vj::DevBuf d_q2[vj::MAX_PASSES];  // stage trees: the tiles' own queue set (enqueue_cascade: split_sets)
     vj::DevBuf d_skip_bits;           // P2 skip modes: visited-window bitmaps of the frames in flight
-    vj::DevBuf d_rois, d_roi_units, d_roi_det;   // regions of interest on the device (vj_detect_chain)
+    vj::DevBuf d_rois, d_roi_units, d_roi_det, d_roi_tiles;   // regions of interest on the device (vj_detect_chain)
+    uint32_t roi_tile_cap = 0;
+    int roi_tile_min_windows = 512;   // region pass: (region, scale) grids of at least this many windows run on LDS tiles (0: never)
     vj::DevBuf d_group;                          // scratch of the device-side grouping (vj_detect_chain, min_neighbors != 0)
     uint32_t roi_unit_cap = 0, roi_det_cap = 0;
     typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t, uint32_t, uint32_t> PlanKey;

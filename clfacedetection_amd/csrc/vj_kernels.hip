@@ -1261,6 +1261,16 @@ __global__ __launch_bounds__(256) void roi_plan_units(RoiArgs r, CascadeArgs a) 
         const int32_t ny = __float2int_rn((float)(R.h - win_h) / step);
         if (nx <= 0 || ny <= 0) continue;
         const uint32_t nwin = (uint32_t)nx * (uint32_t)ny;
+        if (r.tiles != nullptr && scales[slot].tile_rw != 0u && scales[slot].tile_class == 0u && nwin >= r.tile_min_windows && nx < 65536 &&
+            ny < 65536) {
+            // a grid worth staging: tiles of the scale's tile shape inside the region (cascade_tile_roi_pass)
+            const uint32_t tw = scales[slot].tile_tw, th = scales[slot].tile_th;
+            const uint32_t tx = ((uint32_t)nx + tw - 1u) / tw, ty = ((uint32_t)ny + th - 1u) / th;
+            const uint32_t base = atomicAdd(r.n_tiles, tx * ty);
+            for (uint32_t j = 0; j < tx * ty && base + j < r.max_tiles; ++j)
+                r.tiles[base + j] = RoiTile{roi, slot, (j % tx) * tw | ((j / tx) * th) << 16, (uint32_t)nx | (uint32_t)ny << 16};
+            continue;
+        }
         const uint32_t nun = (nwin + UNIT_WINDOWS - 1u) / UNIT_WINDOWS;
         const uint32_t base = atomicAdd(r.n_units, nun);
         for (uint32_t j = 0; j < nun && base + j < r.max_units; ++j)
@@ -1344,6 +1354,9 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_roi_pass(RoiArgs
     }
 }
 
+template <bool COUNT>
+__global__ void cascade_tile_roi_pass(RoiArgs r, CascadeArgs a);   // (defined with the tile kernel below)
+
 template <bool GENERAL>
 static void launch_roi_pass(const RoiArgs& r, const CascadeArgs& a, bool trees, bool count, dim3 g, dim3 b, hipStream_t stream) {
     if (trees) {
@@ -1356,13 +1369,30 @@ static void launch_roi_pass(const RoiArgs& r, const CascadeArgs& a, bool trees, 
 }
 
 int launch_roi_chain(const RoiArgs& r, const CascadeArgs& a, bool from_dets, bool trees, bool count, bool general, int n_blocks,
-                     void* stream_) {
-    hipStream_t stream = (hipStream_t)stream_;
+                     void* stream_, void* stream2_, void* fork_ev_, void* join_ev_) {
+    hipStream_t stream = (hipStream_t)stream_, stream2 = (hipStream_t)stream2_;
     if (from_dets) hipLaunchKernelGGL(dets_to_rois, dim3(256), dim3(256), 0, stream, r);
     hipLaunchKernelGGL(roi_plan_units, dim3(512), dim3(256), 0, stream, r, a);
     dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
-    if (general) launch_roi_pass<true>(r, a, trees, count, g, b, stream);
-    else launch_roi_pass<false>(r, a, trees, count, g, b, stream);
+    // the regions' tiles (LDS / VALU-bound) and the thin units of the region pass (texture-address-bound) side by side on two
+    // streams when the caller lends a second one: the gather pass first, the tile workgroups fill the CUs next to it
+    const bool two = r.tiles != nullptr && stream2 != nullptr;
+    hipStream_t sB = two ? stream2 : stream;
+    if (two) {
+        if (hipEventRecord((hipEvent_t)fork_ev_, stream) != hipSuccess || hipStreamWaitEvent(stream2, (hipEvent_t)fork_ev_, 0) != hipSuccess)
+            return (int)hipGetLastError();
+    }
+    if (general) launch_roi_pass<true>(r, a, trees, count, g, b, sB);
+    else launch_roi_pass<false>(r, a, trees, count, g, b, sB);
+    if (r.tiles != nullptr) {
+        dim3 tg(r.tile_blocks), tb(TILE_WAVES * 64);
+        if (count) hipLaunchKernelGGL((cascade_tile_roi_pass<true>), tg, tb, a.tile_lds_bytes, stream, r, a);
+        else       hipLaunchKernelGGL((cascade_tile_roi_pass<false>), tg, tb, a.tile_lds_bytes, stream, r, a);
+    }
+    if (two) {
+        if (hipEventRecord((hipEvent_t)join_ev_, stream2) != hipSuccess || hipStreamWaitEvent(stream, (hipEvent_t)join_ev_, 0) != hipSuccess)
+            return (int)hipGetLastError();
+    }
     return (int)hipGetLastError();
 }
 
@@ -1826,8 +1856,11 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
     return T;
 }
 
-template <bool TREES, bool COUNT, bool STAGED>
-__global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs a) {
+// ROI: the tiles come from a device-built list of (region, scale, tile) entries (roi_plan_units) instead of a frame's own
+// tile list: a tile then lies inside a region of interest — its window grid is the region's, its origin the region's
+// corner — and the survivors of the last stage go to the region pass's detection list.  Everything else is the same code.
+template <bool TREES, bool COUNT, bool STAGED, bool ROI>
+__device__ __forceinline__ void tile_pass_body(const CascadeArgs& a, const RoiArgs* r_) {
     extern __shared__ __attribute__((aligned(16))) uint32_t lds_dyn[];
     QEntry* lds_q = reinterpret_cast<QEntry*>(lds_dyn);                   // TILE_WAVES * TILE_WAVE_CAP entries
     uint32_t* lds_cnt = lds_dyn + TILE_WAVES * TILE_WAVE_CAP * 2;         // survivors per wave (re-packing)
@@ -1838,7 +1871,7 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
     QEntry* q = lds_q + wib * TILE_WAVE_CAP;
     kptr<ScaleDev> scales = as_k(a.scales);
     kptr<UnitDev> units = as_k(a.tile_units);
-    const uint32_t total_units = a.n_tile_units * a.n_frames;
+    const uint32_t total_units = ROI ? min(*r_->n_tiles, r_->max_tiles) : a.n_tile_units * a.n_frames;
     const uint32_t frame_bytes4 = a.frame_elems * 4u;
 
 #define STAMP(ph) do { if (VJ_STAMPS && threadIdx.x == 0) { unsigned long long t_ = __builtin_amdgcn_s_memtime(); atomicAdd(a.stage_entered + 40 + (ph), t_ - t_last); t_last = t_; } } while (0)
@@ -1879,13 +1912,30 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
     while (u < total_units) {
         uint32_t next_u = 0;
         if (threadIdx.x == 0) next_u = draw();
-        const uint32_t frame = u / a.n_tile_units;
-        const uint32_t r = u - frame * a.n_tile_units;
-        const uint32_t slot = units[r].scale;
-        const uint32_t ix0 = units[r].first & 0xffffu, iy0 = units[r].first >> 16;
+        uint32_t frame, slot, ix0, iy0, nx, ny, ox = 0, oy = 0, roi = 0;
+        if constexpr (ROI) {
+            kptr<RoiTile> rt = as_k(r_->tiles);
+            roi = rt[u].roi;
+            slot = rt[u].slot;
+            ix0 = rt[u].first & 0xffffu;
+            iy0 = rt[u].first >> 16;
+            nx = rt[u].nxy & 0xffffu;
+            ny = rt[u].nxy >> 16;
+            const RoiDev R = r_->rois[roi];
+            frame = __builtin_amdgcn_readfirstlane((uint32_t)R.frame);
+            ox = __builtin_amdgcn_readfirstlane((uint32_t)R.x);
+            oy = __builtin_amdgcn_readfirstlane((uint32_t)R.y);
+        } else {
+            frame = u / a.n_tile_units;
+            const uint32_t r = u - frame * a.n_tile_units;
+            slot = units[r].scale;
+            ix0 = units[r].first & 0xffffu;
+            iy0 = units[r].first >> 16;
+            nx = scales[slot].nx;
+            ny = scales[slot].ny;
+        }
         const float step = scales[slot].step;
         const uint32_t pos_base = scales[slot].pos_base;
-        const uint32_t nx = scales[slot].nx, ny = scales[slot].ny;
         const uint32_t tw = scales[slot].tile_tw, th = scales[slot].tile_th;
         const uint32_t pitch = STAGED ? scales[slot].tile_pitch : 0u, rows = STAGED ? scales[slot].tile_rows : 0u;
         const uint32_t frame_bytes = frame * frame_bytes4;   // < 2^32, checked on the host
@@ -1893,8 +1943,8 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
         const rsrc_t sq_f = make_rsrc(a.sqsum + frame_off, frame_bytes4 * 2u);
         // tile origin in the image: the first window's origin (same expression as below)
-        const uint32_t x0 = __builtin_amdgcn_readfirstlane(window_pos(a, pos_base, ix0, step));
-        const uint32_t y0 = __builtin_amdgcn_readfirstlane(window_pos(a, pos_base, iy0, step));
+        const uint32_t x0 = ox + __builtin_amdgcn_readfirstlane(window_pos(a, pos_base, ix0, step));
+        const uint32_t y0 = oy + __builtin_amdgcn_readfirstlane(window_pos(a, pos_base, iy0, step));
 
         __syncthreads();  // the previous tile's gathers are finished
         STAMP(0);
@@ -1960,13 +2010,13 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
             const uint32_t ty = t / tw, tx = t - ty * tw;
             const uint32_t iy = iy0 + ty, ix = ix0 + tx;
             w_valid[k] = t < t_end && iy < ny && ix < nx;
-            if (a.skip_bits != nullptr && w_valid[k])   // uniform test
+            if (!ROI && a.skip_bits != nullptr && w_valid[k])   // uniform test
                 w_valid[k] = window_visited(a, frame, scales[slot].skip_base, scales[slot].skip_wpr, nx, ix, iy);
             w_lo4[k] = 0u;
             w_q[k] = 0ull;
             if (w_valid[k]) {
-                const uint32_t x = window_pos(a, pos_base, ix, step);
-                const uint32_t y = window_pos(a, pos_base, iy, step);
+                const uint32_t x = ox + window_pos(a, pos_base, ix, step);
+                const uint32_t y = oy + window_pos(a, pos_base, iy, step);
                 // byte offset inside the tile (de-interleaved rows: window origins are even columns)
                 const uint32_t e = y * a.stride + x;
                 // unstaged blocks: byte offset in the batch sum image, as in cascade_pass
@@ -2021,6 +2071,18 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
         // hand a wave's survivors on: detections (dest == n_pass) or the global queue of pass boundary `dest`;
         // tile-local offsets become byte offsets in the batch sum image
         auto flush_wave = [&](const QEntry* qq, uint32_t nn, uint32_t dest_) {
+            if constexpr (ROI) {   // (one pass: whatever survives is a detection of this region)
+                uint32_t g = 0;
+                if (lane == 0) g = atomicAdd(r_->det_count, nn);
+                g = __builtin_amdgcn_readfirstlane(g);
+                for (uint32_t i = lane; i < nn; i += 64u) {
+                    const uint32_t lo = qq[i].off >> 2;
+                    const uint32_t ly = lo / pitch, lc = lo - ly * pitch;
+                    const uint32_t lx = half ? lc * 2u : lc;
+                    if (g + i < r_->det_cap) r_->det[g + i] = RoiDet{frame_bytes + ((y0 + ly) * a.stride + (x0 + lx)) * 4u, slot, roi};
+                }
+                return;
+            }
             const bool is_det = dest_ == a.n_pass;
             const uint32_t part = frame_part(a, frame);
             uint32_t g = 0;
@@ -2152,12 +2214,24 @@ __global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs
     if (VJ_STAMPS && threadIdx.x == 0) atomicAdd(a.stage_entered + 38, ~0ull);
 }
 
+template <bool TREES, bool COUNT, bool STAGED>
+__global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_pass(CascadeArgs a) {
+    tile_pass_body<TREES, COUNT, STAGED, false>(a, nullptr);
+}
+
+// The tile kernel inside regions of interest (vj_detect_chain / vj_detect_rois with many or large regions; stump cascades).
+template <bool COUNT>
+__global__ __launch_bounds__(TILE_WAVES * 64) void cascade_tile_roi_pass(RoiArgs r, CascadeArgs a) {
+    tile_pass_body<false, COUNT, true, true>(a, &r);
+}
+
 // The tile kernel uses up to the CU's whole 160 KiB of dynamic LDS; HIP caps a kernel at 64 KiB until the attribute
 // is raised, and the attribute belongs to the (function, device) pair: vj_env_create calls this once per environment,
 // with that environment's device current.
 int prepare_tile_kernels() {
     const int max_lds = 160 * 1024;
-    const void* fns[] = {(const void*)cascade_tile_pass<false, false, true>, (const void*)cascade_tile_pass<false, true, true>,
+    const void* fns[] = {(const void*)cascade_tile_roi_pass<false>, (const void*)cascade_tile_roi_pass<true>,
+                         (const void*)cascade_tile_pass<false, false, true>, (const void*)cascade_tile_pass<false, true, true>,
                          (const void*)cascade_tile_pass<true, false, true>,  (const void*)cascade_tile_pass<true, true, true>,
                          (const void*)cascade_tile_pass<false, false, false>, (const void*)cascade_tile_pass<false, true, false>};
     for (const void* f : fns) {
