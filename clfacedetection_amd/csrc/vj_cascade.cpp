@@ -293,6 +293,8 @@ StageProgram build_stage_program(const vj_cascade& c) {
     sp.on_fail.resize(n);
     sp.n_nodes.assign(n, 0);
     sp.n_rects.assign(n, 0);
+    sp.n_roots.assign(n, 0);
+    sp.n_root_rects.assign(n, 0);
     sp.first_node.assign(n, 0);
     for (int s = 0; s < n; ++s) {
         const vj_stage_desc& sd = c.stages[s];
@@ -306,6 +308,8 @@ StageProgram build_stage_program(const vj_cascade& c) {
         for (int t = 0; t < sd.n_trees; ++t) {
             const vj_tree_desc& td = c.trees[sd.first_tree + t];
             sp.n_nodes[s] += (uint32_t)td.n_nodes;
+            sp.n_roots[s] += 1u;
+            sp.n_root_rects[s] += (uint32_t)c.nodes[td.first_node].n_rects;
             for (int k = 0; k < td.n_nodes; ++k) sp.n_rects[s] += (uint32_t)c.nodes[td.first_node + k].n_rects;
         }
     }

@@ -194,6 +194,7 @@ struct CascadeArgs {
     uint32_t  det_cap;
     uint32_t  signed_mean;      // VJ_FLAG_SIGNED_MEAN
     unsigned long long* stage_entered;  // [VJ_MAX_STAGES] when counting, else null
+    unsigned long long* tree_ctr;       // counting, multi-node trees: [0] nodes below the root that a window's walk visited, [1] their rectangles
     // P2 skip modes (VJ_FLAG_SKIP_LIST / VJ_FLAG_SKIP_ROW; clod.cpp:729-732, :1430): a bitmap of the grid windows the
     // reference's sequential CPU loops visit, built by skip_fail_bits + skip_resolve before the cascade passes;
     // null = every grid window (the OpenCL kernel's contract)

@@ -989,6 +989,7 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
         ca.det_cap = L->det_cap;
         ca.signed_mean = (p.flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
         ca.stage_entered = d_stage_entered;
+        ca.tree_ctr = d_stage_entered;       // array 0 is spare: [0], [1] = the first cascade's visited child nodes / their rectangles
         ca.n_pass = (uint32_t)n_pass;
         for (size_t ps = 0; ps <= n_pass; ++ps) ca.pass_begin[ps] = pl->pass_bounds[ps];
         for (size_t ps = 1; ps < n_pass; ++ps) {
@@ -1314,9 +1315,14 @@ static int finish_batch(vj_env* e, Lane* L, Plan* pl, int f0, int W, int H, cons
             fprintf(stderr, "\n");
         }
 #endif
-        if (count)
+        if (count) {
             for (size_t s = 0; s < pl->stages.size(); ++s)
                 for (int l = 1; l <= VJ_MAX_LAUNCHES; ++l) ctr->stage_entered[s] += se_all[(size_t)l * VJ_MAX_STAGES + s];
+            // multi-node trees: nodes below the roots that the walks visited, and their rectangles — parked in the two derived
+            // fields until fill_counters prices the roots (every entering window evaluates those) and adds these
+            ctr->stump_evals += se_all[0];
+            ctr->gather_bytes += se_all[1];
+        }
         std::vector<DetEntry> raw(n_det);
         const uint32_t have = std::min(n_det, L->det_copied);
         if (have) memcpy(raw.data(), (const char*)L->h_pinned + ((counts_bytes + 255) & ~(size_t)255), (size_t)have * sizeof(DetEntry));
@@ -1352,12 +1358,15 @@ static void fill_counters(Plan* pl, int n_frames, const vj_params& p, vj_result*
     if (!(p.flags & VJ_FLAG_COUNTERS)) return;
     vj_counters& k = out->counters;
     k.windows = pl->windows_per_frame * (uint64_t)n_frames;
-    uint64_t rect_evals = 0;
+    // node evaluations as the oracle counts them: every node a window's walk visits.  Stumps: every node of an
+    // entered stage.  Multi-node trees: the root of every tree of an entered stage + the nodes below the roots that the
+    // counted kernels saw visited (finish_batch parked those in the two derived fields).
+    const uint64_t child_nodes = k.stump_evals, child_rects = k.gather_bytes;
+    uint64_t rect_evals = pl->trees ? child_rects : 0;
+    k.stump_evals = pl->trees ? child_nodes : 0;
     for (size_t s = 0; s < pl->stages.size(); ++s) {
-        // exact for stump cascades; for multi-node trees this is the upper bound
-        // (every node of every tree) — see DESIGN.md
-        k.stump_evals += k.stage_entered[s] * pl->prog.n_nodes[s];
-        rect_evals += k.stage_entered[s] * pl->prog.n_rects[s];
+        k.stump_evals += k.stage_entered[s] * (pl->trees ? pl->prog.n_roots[s] : pl->prog.n_nodes[s]);
+        rect_evals += k.stage_entered[s] * (pl->trees ? pl->prog.n_root_rects[s] : pl->prog.n_rects[s]);
     }
     k.gather_bytes = 48ull * k.windows + 16ull * rect_evals;
 }
@@ -1479,6 +1488,7 @@ static void fill_region_args(vj_env* e, Lane* L, Plan* pl2, const vj_cascade* se
     ca.sp_tail_max = (uint32_t)std::max(0, std::min(e->sp_tail_max, 48));
     ca.max_stage_nodes = pl2->max_stage_nodes;
     ca.stage_entered = (unsigned long long*)(roi_counts + 8);
+    ca.tree_ctr = (unsigned long long*)((uint32_t*)L->d_counts.p + CountsLayout::stage_off_u32) + 2;   // the spare array's [2], [3]: the region pass's
     // Regions with large grids at the small scales (many raw candidates, big faces) run those grids on the tile kernel
     // (cascade_tile_roi_pass: tiles of the second cascade's two-per-CU tile scales, laid inside the region): stump cascades
     // whose plan has such tiles.  The caller sizes e->d_roi_tiles and zeroes the eight ticket counters.
@@ -1533,6 +1543,7 @@ static int detect_rois_on_device(vj_env* e, const vj_cascade* c, const vj_image*
     const uint64_t fbytes = (uint64_t)pl2->frame_elems * 4u;
     struct Det2 { int roi; uint32_t slot, x, y; };
     std::vector<Det2> dets2;
+    uint64_t child2_nodes = 0, child2_rects = 0;   // counted calls, multi-node trees: visited nodes below the roots (second cascade)
     for (int f0 = 0; f0 < n_frames; f0 += (int)max_frames) {
         const int nf = (int)std::min<uint64_t>(max_frames, (uint64_t)(n_frames - f0));
         std::vector<RoiDev> regions;
@@ -1560,6 +1571,7 @@ static int detect_rois_on_device(vj_env* e, const vj_cascade* c, const vj_image*
             HIP_TRY(hipMemsetAsync((uint32_t*)L->d_counts.p + (CountsLayout::q_counts - 40u), 0, 8 * 4, e->stream));   // tile tickets of the region pass
             uint32_t* roi_counts = (uint32_t*)L->d_counts.p + CountsLayout::roi_off_u32;
             HIP_TRY(hipMemsetAsync(roi_counts, 0, (8 + (size_t)VJ_MAX_STAGES * 2) * 4, e->stream));
+            HIP_TRY(hipMemsetAsync((uint32_t*)L->d_counts.p + CountsLayout::stage_off_u32 + 4, 0, 16, e->stream));   // the region pass's tree counters
             HIP_TRY(hipMemcpyAsync(roi_counts, &n_reg, 4, hipMemcpyHostToDevice, e->stream));
             RoiArgs ra;
             CascadeArgs ca;
@@ -1573,6 +1585,8 @@ static int detect_rois_on_device(vj_env* e, const vj_cascade* c, const vj_image*
             }
             HIP_TRY(hipEventRecord(L->launch_ev[2 * VJ_MAX_LAUNCHES - 1], e->stream));
             HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32, roi_counts, (8 + (size_t)VJ_MAX_STAGES * 2) * 4,
+                                   hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::stage_off_u32 + 4, (uint32_t*)L->d_counts.p + CountsLayout::stage_off_u32 + 4, 16,
                                    hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipEventRecord(L->done, e->stream));
             HIP_TRY(hipEventSynchronize(L->done));
@@ -1613,6 +1627,9 @@ static int detect_rois_on_device(vj_env* e, const vj_cascade* c, const vj_image*
         }
         if (count2) {
             const unsigned long long* se = (const unsigned long long*)((const uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 8);
+            const unsigned long long* tc = (const unsigned long long*)((const uint32_t*)L->h_pinned + CountsLayout::stage_off_u32) + 2;
+            child2_nodes += tc[0];
+            child2_rects += tc[1];
             for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) out->counters.stage_entered[s2] += se[s2];
         }
     }
@@ -1636,9 +1653,13 @@ static int detect_rois_on_device(vj_env* e, const vj_cascade* c, const vj_image*
         vj_counters& k = out->counters;
         k.windows = k.stage_entered[0];
         uint64_t rect_evals = 0;
-        for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) {
-            k.stump_evals += k.stage_entered[s2] * pl2->prog.n_nodes[s2];
-            rect_evals += k.stage_entered[s2] * pl2->prog.n_rects[s2];
+        for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) {   // (as fill_counters: roots on the host, visited child nodes from the device)
+            k.stump_evals += k.stage_entered[s2] * (pl2->trees ? pl2->prog.n_roots[s2] : pl2->prog.n_nodes[s2]);
+            rect_evals += k.stage_entered[s2] * (pl2->trees ? pl2->prog.n_root_rects[s2] : pl2->prog.n_rects[s2]);
+        }
+        if (pl2->trees) {
+            k.stump_evals += child2_nodes;
+            rect_evals += child2_rects;
         }
         k.gather_bytes = 48ull * k.windows + 16ull * rect_evals;
     }
@@ -2317,6 +2338,7 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
     std::vector<vj_rect> grouped1;       // grouped mode: the first result, as the device grouped it
     struct Det2 { int roi; uint32_t slot, x, y; };
     std::vector<Det2> dets2;
+    uint64_t child2_nodes = 0, child2_rects = 0;   // counted calls, multi-node trees: visited nodes below the roots (second cascade)
     const bool count2 = (p_second->flags & VJ_FLAG_COUNTERS) != 0;
     const uint32_t stride = (uint32_t)W + 1u;
     const uint64_t fbytes = (uint64_t)pl1->frame_elems * 4u;
@@ -2399,6 +2421,8 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
             HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 6, roi_counts + 6, 4, hipMemcpyDeviceToHost, e->stream));   // region tiles
             HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 8, roi_counts + 8, (size_t)VJ_MAX_STAGES * 2 * 4,
                                    hipMemcpyDeviceToHost, e->stream));
+            HIP_TRY(hipMemcpyAsync((uint32_t*)L->h_pinned + CountsLayout::stage_off_u32 + 4, (uint32_t*)L->d_counts.p + CountsLayout::stage_off_u32 + 4, 16,
+                                   hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipEventRecord(L->done, e->stream));
             HIP_TRY(hipEventSynchronize(L->done));
             const uint32_t* hc = (const uint32_t*)L->h_pinned;
@@ -2479,6 +2503,9 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
         out_second->timing.n_cascade_launches = 1;
         if (count2) {
             const unsigned long long* se = (const unsigned long long*)((const uint32_t*)L->h_pinned + CountsLayout::roi_off_u32 + 8);
+            const unsigned long long* tc = (const unsigned long long*)((const uint32_t*)L->h_pinned + CountsLayout::stage_off_u32) + 2;
+            child2_nodes += tc[0];
+            child2_rects += tc[1];
             for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) out_second->counters.stage_entered[s2] += se[s2];
         }
     }
@@ -2525,9 +2552,13 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
         vj_counters& k = out_second->counters;
         k.windows = k.stage_entered[0];
         uint64_t rect_evals = 0;
-        for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) {
-            k.stump_evals += k.stage_entered[s2] * pl2->prog.n_nodes[s2];
-            rect_evals += k.stage_entered[s2] * pl2->prog.n_rects[s2];
+        for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) {   // (as fill_counters: roots on the host, visited child nodes from the device)
+            k.stump_evals += k.stage_entered[s2] * (pl2->trees ? pl2->prog.n_roots[s2] : pl2->prog.n_nodes[s2]);
+            rect_evals += k.stage_entered[s2] * (pl2->trees ? pl2->prog.n_root_rects[s2] : pl2->prog.n_rects[s2]);
+        }
+        if (pl2->trees) {
+            k.stump_evals += child2_nodes;
+            rect_evals += child2_rects;
         }
         k.gather_bytes = 48ull * k.windows + 16ull * rect_evals;
     }

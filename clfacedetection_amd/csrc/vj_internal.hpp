@@ -31,6 +31,7 @@ struct StageProgram {
     std::vector<int32_t> on_pass, on_fail;
     std::vector<uint32_t> n_nodes;      // nodes per stage
     std::vector<uint32_t> n_rects;      // sum of n_rects over the stage's nodes
+    std::vector<uint32_t> n_roots, n_root_rects;   // trees per stage and the rectangles of their root nodes (every entering window evaluates those)
     std::vector<uint32_t> first_node;   // flat node index of the stage's first node
 };
 enum { STAGE_ACCEPT = -1, STAGE_REJECT = -2 };

@@ -411,10 +411,25 @@ __device__ __forceinline__ float node_rect_sum(const Img& img, const NodeRecDev&
 template <typename Img>
 __device__ __forceinline__ void node_rect_sum_pair(const Img& img, const NodeRecDev& ra, const NodeRecDev& rb, uint32_t off,
                                                    float& sum_a, float& sum_b);
-template <int NC, typename Img>
+// (COUNT: cnt[c] += {nodes below the root that window c's walk visits, their rectangles} — the oracle's stump_evals / rect_evals
+// count visited nodes; the roots are every entering window's and are priced on the host)
+template <int NC, bool COUNT = false, typename Img>
 __device__ __forceinline__ void stage_sum_tree2_multi(const Img& img, kptr<NodeRecDev> tab, uint32_t n_trees,
                                                       const uint32_t (&off)[NC], const float (&var)[NC],
-                                                      float (&stage_sum)[NC]);   // (defined with the tile kernel's sweeps)
+                                                      float (&stage_sum)[NC], uint32_t (*cnt)[2] = nullptr);   // (defined with the tile kernel's sweeps)
+
+// Adds the lanes' visited-node counts of a counted sweep to CascadeArgs::tree_ctr (lanes outside the population pass 0).
+__device__ __forceinline__ void tree_count_flush(const CascadeArgs& a, uint32_t nodes, uint32_t rects, uint32_t lane) {
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) {
+        nodes += (uint32_t)__shfl_xor((int)nodes, d, 64);
+        rects += (uint32_t)__shfl_xor((int)rects, d, 64);
+    }
+    if (lane == 0 && (nodes | rects) != 0u) {
+        atomicAdd(a.tree_ctr, (unsigned long long)nodes);
+        atomicAdd(a.tree_ctr + 1, (unsigned long long)rects);
+    }
+}
 
 // One stump-based stage on one window (clod.cl:49-82).  `tab` points at the stage's
 // first node record of the wave's scale; every table value is wave-uniform.  Two stumps per step: their 16 (24)
@@ -525,9 +540,9 @@ __device__ __forceinline__ void stage_sum_stumps_multi(const Img& img, kptr<Node
 // f32 arithmetic.  Nodes of a tree are stored consecutively and a child always has a
 // larger index than its parent, so a tree is evaluated by visiting its records in
 // order, each with the lanes whose walk currently sits on it; the table stays uniform.
-template <typename Img>
+template <bool COUNT = false, typename Img>
 __device__ __forceinline__ float stage_sum_trees(const Img& img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
-                                                 float var) {
+                                                 float var, uint32_t* cnt = nullptr) {
     float stage_sum = 0.0f;
     uint32_t cur = 0;     // node (inside the current tree) this lane evaluates next
     uint32_t k = 0;       // position of the record inside its tree (uniform)
@@ -537,6 +552,10 @@ __device__ __forceinline__ float stage_sum_trees(const Img& img, kptr<NodeRecDev
         const NodeRecDev r = tab[j];
         const uint32_t flags = r[7] >> 16;
         if (!done && cur == k) {
+            if (COUNT && k != 0u) {
+                cnt[0] += 1u;
+                cnt[1] += __uint_as_float(r[10]) != 0.0f ? 3u : 2u;
+            }
             const float t = __uint_as_float(r[11]) * var;
             const float sum = node_rect_sum(img, r, off);
             const bool go_left = sum < t;  // idx = sum < t ? left : right
@@ -560,10 +579,10 @@ __device__ __forceinline__ float stage_sum_trees(const Img& img, kptr<NodeRecDev
     return stage_sum;
 }
 
-template <bool TREES, typename Img>
+template <bool TREES, bool COUNT = false, typename Img>
 __device__ __forceinline__ float stage_sum_of(const Img& img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
-                                              float var, bool pairs = true) {
-    if (TREES) return stage_sum_trees(img, tab, n_nodes, off, var);
+                                              float var, bool pairs = true, uint32_t* cnt = nullptr) {
+    if (TREES) return stage_sum_trees<COUNT>(img, tab, n_nodes, off, var, cnt);
     return stage_sum_stumps(img, tab, n_nodes, off, var, pairs);
 }
 
@@ -732,7 +751,12 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
                     off[c] = e[c].off;
                     var[c] = e[c].var;
                 }
-                stage_sum_tree2_multi<2>(img, tab, n_nodes >> 1, off, var, sum);
+                uint32_t cnt2[2][2] = {{0u, 0u}, {0u, 0u}};
+                stage_sum_tree2_multi<2, COUNT>(img, tab, n_nodes >> 1, off, var, sum, cnt2);
+                if (COUNT) {
+                    const bool a0 = base + lane < n, a1 = base + 64u + lane < n;
+                    tree_count_flush(a, (a0 ? cnt2[0][0] : 0u) + (a1 ? cnt2[1][0] : 0u), (a0 ? cnt2[0][1] : 0u) + (a1 ? cnt2[1][1] : 0u), lane);
+                }
                 __builtin_amdgcn_wave_barrier();
 #pragma unroll
                 for (int c = 0; c < 2; ++c) {
@@ -779,17 +803,19 @@ __device__ __forceinline__ uint32_t sweep_stages(const CascadeArgs& a, const Img
             const bool act = i < n;
             const QEntry e = q[act ? i : 0u];
             bool pass = false;
+            uint32_t cnt1[1][2] = {{0u, 0u}};
             if (act) {
                 if (TREES && a.tree2) {   // two-node trees: both nodes' gathers in flight (tile sweeps and global-gather sweeps alike)
                     const uint32_t off1[1] = {e.off};
                     const float var1[1] = {e.var};
                     float sum1[1];
-                    stage_sum_tree2_multi<1>(img, tab, n_nodes >> 1, off1, var1, sum1);
+                    stage_sum_tree2_multi<1, COUNT>(img, tab, n_nodes >> 1, off1, var1, sum1, cnt1);
                     pass = sum1[0] >= threshold;
                 } else {
-                    pass = stage_sum_of<TREES>(img, tab, n_nodes, e.off, e.var, a.gather_pairs == 2u || (a.gather_pairs == 1u && n <= 64u)) >= threshold;
+                    pass = stage_sum_of<TREES, COUNT>(img, tab, n_nodes, e.off, e.var, a.gather_pairs == 2u || (a.gather_pairs == 1u && n <= 64u), cnt1[0]) >= threshold;
                 }
             }
+            if (TREES && COUNT) tree_count_flush(a, cnt1[0][0], cnt1[0][1], lane);
             if (!MULTI && fail.base != nullptr) {   // uniform: this segment's rejects continue elsewhere
                 const unsigned long long fm = __ballot(act && !pass);
                 if (fm != 0ull) {
@@ -877,7 +903,9 @@ __device__ __forceinline__ void run_stages_general_to(const CascadeArgs& a, rsrc
             const QEntry e = q[act ? i : 0u];
             int32_t t = tgt[act ? i : 0u];
             const bool here = act && t == (int32_t)s;
-            if (here) t = (stage_sum_of<TREES>(GlobalImg{img}, tab, n_nodes, e.off, e.var) >= threshold) ? on_pass : on_fail;
+            uint32_t cntg[2] = {0u, 0u};
+            if (here) t = (stage_sum_of<TREES, COUNT>(GlobalImg{img}, tab, n_nodes, e.off, e.var, true, cntg) >= threshold) ? on_pass : on_fail;
+            if (TREES && COUNT) tree_count_flush(a, cntg[0], cntg[1], lane);
             const bool keep = act && t >= 0;
             const unsigned long long acc_mask = __ballot(act && t == -1);  // accepted: falls off the tree's end
             if (acc_mask != 0ull) emit(acc_mask, act && t == -1, e.off);
@@ -1660,10 +1688,10 @@ __device__ __forceinline__ float tree2_value(const Img& img, const NodeRecDev& r
 
 // One stage of two-node trees on NC chunks of windows: the two records of a tree are fetched once for all
 // chunks (next tree prefetched); per window the values are added in tree order, as stage_sum_trees does.
-template <int NC, typename Img>
+template <int NC, bool COUNT, typename Img>
 __device__ __forceinline__ void stage_sum_tree2_multi(const Img& img, kptr<NodeRecDev> tab, uint32_t n_trees,
                                                       const uint32_t (&off)[NC], const float (&var)[NC],
-                                                      float (&stage_sum)[NC]) {
+                                                      float (&stage_sum)[NC], uint32_t (*cnt)[2]) {
 #pragma unroll
     for (int c = 0; c < NC; ++c) stage_sum[c] = 0.0f;
     NodeRecDev r0 = tab[0], r1 = tab[1];
@@ -1674,6 +1702,10 @@ __device__ __forceinline__ void stage_sum_tree2_multi(const Img& img, kptr<NodeR
         for (int c = 0; c < NC; ++c) {
             uint32_t code;
             stage_sum[c] += tree2_value(img, r0, r1, off[c], var[c], code);
+            if (COUNT && (code & 2u)) {   // the walk went through the child
+                cnt[c][0] += 1u;
+                cnt[c][1] += __uint_as_float(r1[10]) != 0.0f ? 3u : 2u;
+            }
         }
         r0 = n0;
         r1 = n1;
@@ -1728,7 +1760,9 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
                     const uint32_t off1[1] = {e.off};
                     const float var1[1] = {e.var};
                     float sum1[1];
-                    stage_sum_tree2_multi<1>(img, tab, n, off1, var1, sum1);
+                    uint32_t cnt1[1][2] = {{0u, 0u}};
+                    stage_sum_tree2_multi<1, COUNT>(img, tab, n, off1, var1, sum1, cnt1);
+                    if (COUNT) tree_count_flush(a, valid ? cnt1[0][0] : 0u, valid ? cnt1[0][1] : 0u, lane);
                     pass = valid && sum1[0] >= thr_s;
                 } else {
                     pass = valid && stage_sum_stumps(img, tab, n, e.off, e.var) >= thr_s;
@@ -1738,6 +1772,7 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
                 float psum = 0.0f;
                 uint32_t* xw = lds_x + wib * 320u;   // [0,64) sums, [64 + 64 w, ...) verdict word w
                 if (TREE2) {
+                    uint32_t c_nodes = 0u, c_rects = 0u;
                     for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += PER_WORD, ++wd) {
                         const uint32_t m = min(PER_WORD, j1 - w0);
                         uint32_t bw = 0u;
@@ -1747,12 +1782,17 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
                             const NodeRecDev n0 = tab[2u * tn], n1 = tab[2u * tn + 1u];
                             uint32_t code;
                             psum += tree2_value(img, r0, r1, e.off, e.var, code);
+                            if (COUNT && (code & 2u)) {
+                                c_nodes += 1u;
+                                c_rects += __uint_as_float(r1[10]) != 0.0f ? 3u : 2u;
+                            }
                             bw |= code << (2u * k);
                             r0 = n0;
                             r1 = n1;
                         }
                         xw[64u + wd * 64u + lane] = bw;
                     }
+                    if (COUNT) tree_count_flush(a, valid ? c_nodes : 0u, valid ? c_rects : 0u, lane);
                 } else {
                     for (uint32_t w0 = j0, wd = 0; w0 < j1; w0 += 32u, ++wd) {
                         const uint32_t m = min(32u, j1 - w0);

@@ -231,8 +231,8 @@ typedef struct vj_rect {       /* CLODWeightedRect (clod.h:39-42) + provenance  
 #define VJ_MAX_STAGES 64
 typedef struct vj_counters {
     uint64_t windows;          /* candidate windows enumerated                  */
-    uint64_t stump_evals;      /* tree-node evaluations: every node of every stage a window enters (exact for
-                                  stump cascades; an upper bound of the walk's visits for multi-node trees) */
+    uint64_t stump_evals;      /* tree-node evaluations as SURVEY.md §8d counts them: the nodes a window's walk visits
+                                  (every node of an entered stage for stumps; root + visited children for trees) */
     uint64_t gather_bytes;     /* 48*windows + 16*sum(nrects)   */
     uint64_t stage_entered[VJ_MAX_STAGES]; /* windows entering each stage       */
 } vj_counters;

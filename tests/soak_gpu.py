@@ -91,6 +91,8 @@ while time.time() < t_end:
             for f in range(nb):
                 ok &= rows(r.rects[r.rects["frame"] == f]) == rows(ro)
             ok &= r.stage_entered == [v * nb for v in st["stage_entered"]]
+            if mode == "grid":      # node evaluations / algorithmic bytes by the oracle's definition (visited nodes), trees included
+                ok &= r.stump_evals == st["stump_evals"] * nb and r.gather_bytes == st["gather_bytes"] * nb
             desc += (mn, mx, sf)
         elif mode == "opencv":
             sf = [1.1, 1.2, 1.3][int(rng.integers(0, 3))]
