@@ -477,6 +477,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 if ((rc = e->d_skip_bits.ensure(bits_bytes))) return rc;
                 if ((rc = e->d_cv_accept.ensure(bits_bytes))) return rc;
                 tq_cap = (uint32_t)std::min<uint64_t>(pl->tile_windows * (uint64_t)nf / 4u + 4096u, 1ull << 27);
+                if (e->cv_tree_queue_cap > 0) tq_cap = (uint32_t)e->cv_tree_queue_cap;   // (tests: force the overflow path)
                 if ((rc = e->d_cv_tq.ensure((size_t)tq_cap * sizeof(CvTreeEntry)))) return rc;
                 HIP_TRY(hipMemsetAsync(e->d_skip_bits.p, 0, bits_bytes, e->stream));
                 HIP_TRY(hipMemsetAsync(e->d_cv_accept.p, 0, bits_bytes, e->stream));

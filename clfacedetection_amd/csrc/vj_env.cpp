@@ -1836,6 +1836,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         e->tree_split_queues = atoi(value) != 0;
         return VJ_OK;
     }
+    if (strcmp(key, "cv_tree_queue_cap") == 0) {
+        e->cv_tree_queue_cap = std::max(0, atoi(value));
+        return VJ_OK;
+    }
     if (strcmp(key, "roi_tiles") == 0) {   // region pass: smallest (region, scale) grid that runs on LDS tiles (0: none)
         e->roi_tile_min_windows = std::max(0, atoi(value));
         return VJ_OK;

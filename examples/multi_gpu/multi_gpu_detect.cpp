@@ -66,6 +66,8 @@ int main(int argc, char** argv) {
             vj_env_destroy(env);
         });
     for (auto& t : th) t.join();
+    int rccl_ranks = 0;   // what the communicator itself says (1 on a one-GPU box: RCCL does not take two ranks on one device)
+    CHECK(ncclCommCount(comms[0], &rccl_ranks) == ncclSuccess);
     for (auto& c : comms) ncclCommDestroy(c);
 
     // reference: the whole batch on device 0
@@ -82,8 +84,8 @@ int main(int argc, char** argv) {
             ok = g[i].x == whole.rects[i].x && g[i].y == whole.rects[i].y && g[i].w == whole.rects[i].w && g[i].frame == whole.rects[i].frame &&
                  g[i].scale_idx == whole.rects[i].scale_idx;
     }
-    printf("multi_gpu_detect: %d device(s), %d frames, %u rectangles gathered on every rank: %s\n", n_dev, n_frames, whole.count,
-           ok ? "OK" : "MISMATCH");
+    printf("multi_gpu_detect: %d device(s), rccl_ranks %d, %d frames, %u rectangles gathered on every rank: %s\n", n_dev, rccl_ranks, n_frames,
+           whole.count, ok ? "OK" : "MISMATCH");
     vj_result_free(&whole);
     vj_env_destroy(env0);
     vj_cascade_free(casc);

@@ -47,6 +47,10 @@ def test_native_multi_gpu_host_with_rccl(lib, tmp_path):
           f"-Wl,-rpath,{LIBDIR}", "-o", exe])
     out = _run([exe], env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
     assert "OK" in out and "MISMATCH" not in out
+    import re
+    m = re.search(r"(\d+) device\(s\), rccl_ranks (\d+)", out)
+    assert m and m.group(1) == m.group(2)          # the all-gather spanned as many ranks as the box has devices (1 here)
+    print(out.strip().splitlines()[-1])
 
 
 def _rank(rank, world, port, mode, q):
