@@ -323,7 +323,7 @@ int  vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int 
  * THE DEVICE (cv::groupRectangles per frame, as vj_detect groups them on the host: same classes, same
  * averages, same order) and the grouped faces are the regions.  out_first: as vj_detect with the same
  * parameters.  out_second: rect.frame = index of the region in out_first->rects, x / y relative to the
- * region's origin.  `second` must be a linear cascade (stumps or trees).                              */
+ * region's origin.  `second` may be any cascade of upright features (stumps, trees, stage trees).        */
 int  vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second, const vj_image* frames,
                      int n_frames, const vj_params* p_first, const vj_params* p_second, vj_result* out_first,
                      vj_result* out_second);
