@@ -29,7 +29,7 @@ struct CvScaleHost {
 };
 
 // Everything that depends on (cascade, frame size, parameters) only: scales, feature tables, stage records, row list.
-static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_cv_params* p, CvPlan* pl) {
+static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_cv_params* p, bool small_batch, CvPlan* pl) {
     if ((int)c->stages.size() > VJ_MAX_STAGES || c->stages.empty()) {
         set_error("cascade has %zu stages; 1..%d are supported", c->stages.size(), VJ_MAX_STAGES);
         return VJ_ERR_LIMIT;
@@ -107,6 +107,14 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
     // (a stage tree's row kernel evaluates the whole tree at every grid position and is far slower per window than the tiles'
     // prefix: trees send every scale they can to tiles and leave the row kernel two workgroups per CU)
     pl->row_blocks = is_tree ? e->cv_row_blocks_tree : e->cv_row_blocks;
+    // a call of <= 4 frames is bound by latency, not by the balance of two saturated chains: one row-kernel workgroup per CU
+    // and every scale that has a tile of 512 windows on tiles (one 1080p frame: 2.4 -> 2.0 ms)
+    int min_windows = is_tree ? e->cv_tile_min_windows_tree : e->cv_tile_min_windows, min_windows0 = e->cv_tile_min_windows0;
+    if (small_batch && !is_tree) {
+        pl->row_blocks = 1;
+        min_windows = std::min(min_windows, 512);
+        min_windows0 = std::min(min_windows0, 1024);
+    }
     const size_t n_nodes = c->nodes.size();
     std::vector<CvScaleDev>& scales = pl->scales;
     scales.assign(hs.size(), CvScaleDev{});
@@ -237,7 +245,7 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
                         if (nwin > best_n) { best_n = nwin; b_tw = tw; b_th = th; b_pitch = pitch; b_rows = trows; }
                     }
                 // a class-0 tile must be worth two workgroups per CU; else try the larger class
-                if (best_n >= (uint32_t)(cls == 0 ? e->cv_tile_min_windows0 : is_tree ? e->cv_tile_min_windows_tree : e->cv_tile_min_windows))
+                if (best_n >= (uint32_t)(cls == 0 ? min_windows0 : min_windows))
                     b_cls = cls;
                 else
                     best_n = 0;
@@ -345,10 +353,11 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
     return VJ_OK;
 }
 
-static int get_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_cv_params* p, CvPlan** out) {
+static int get_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_cv_params* p, int n_frames, CvPlan** out) {
     uint64_t sf_bits;
     memcpy(&sf_bits, &p->scale_factor, 8);
-    const vj_env::CvPlanKey key(c->uid, W, H, p->min_w, p->min_h, sf_bits);
+    const bool small_batch = n_frames <= 4;
+    const vj_env::CvPlanKey key(c->uid, W, H, p->min_w, p->min_h, sf_bits, small_batch ? 1 : 0);
     auto it = e->cv_plans.find(key);
     if (it != e->cv_plans.end()) {
         it->second->last_used = ++e->plan_tick;
@@ -366,7 +375,7 @@ static int get_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_cv
         }
     }
     auto pl = std::make_unique<CvPlan>();
-    const int rc = build_cv_plan(e, c, W, H, p, pl.get());
+    const int rc = build_cv_plan(e, c, W, H, p, small_batch, pl.get());
     if (rc) {
         pl->release_device();
         return rc;
@@ -411,7 +420,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
         }
     HIP_TRY(hipSetDevice(e->device));
     CvPlan* pl;
-    int rc = get_cv_plan(e, c, W, H, p, &pl);
+    int rc = get_cv_plan(e, c, W, H, p, n_frames, &pl);
     if (rc) return rc;
     const std::vector<CvScaleDev>& scales = pl->scales;
     const StageProgram& prog = pl->prog;

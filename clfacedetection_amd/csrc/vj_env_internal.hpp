@@ -214,7 +214,7 @@ struct vj_env {
     typedef std::tuple<PlanKey, int> BalanceKey;    // the plan key with split = 0, frames per call
     std::map<BalanceKey, Balance> balance;
     bool auto_balance = true, tile_split_set = false;
-    typedef std::tuple<uint64_t, int, int, int, int, uint64_t> CvPlanKey;   // cascade uid, W, H, min size, bits of the scale factor
+    typedef std::tuple<uint64_t, int, int, int, int, uint64_t, int> CvPlanKey;   // cascade uid, W, H, min size, bits of the scale factor, call of <= 4 frames
     std::map<CvPlanKey, std::unique_ptr<vj::CvPlan>> cv_plans;
     vj::DevBuf d_cv_det, d_cv_counts;   // vj_detect_opencv: detection list and counters
     vj::DevBuf d_cv_accept, d_cv_tq;    // ... stage trees on tiles: accept bitmap, the queue of the prefix's survivors
