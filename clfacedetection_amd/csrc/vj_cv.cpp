@@ -485,8 +485,10 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 const size_t bits_bytes = (size_t)pl->bits_frame_words * 8u * (size_t)nf;
                 if ((rc = e->d_skip_bits.ensure(bits_bytes))) return rc;
                 if ((rc = e->d_cv_accept.ensure(bits_bytes))) return rc;
-                tq_cap = (uint32_t)std::min<uint64_t>(pl->tile_windows * (uint64_t)nf / 4u + 4096u, 1ull << 27);
-                if (e->cv_tree_queue_cap > 0) tq_cap = (uint32_t)e->cv_tree_queue_cap;   // (tests: force the overflow path)
+                // room for 1 / 2^shift of the tile windows (a few percent survive the prefix); an overflow halves the shift and
+                // runs the call again; a forced capacity (tests) falls back to the rows instead
+                tq_cap = (uint32_t)std::min<uint64_t>(((pl->tile_windows * (uint64_t)nf) >> e->cv_tq_shift) + 4096u, 1ull << 28);
+                if (e->cv_tree_queue_cap > 0) tq_cap = (uint32_t)e->cv_tree_queue_cap;
                 if ((rc = e->d_cv_tq.ensure((size_t)tq_cap * sizeof(CvTreeEntry)))) return rc;
                 HIP_TRY(hipMemsetAsync(e->d_skip_bits.p, 0, bits_bytes, e->stream));
                 HIP_TRY(hipMemsetAsync(e->d_cv_accept.p, 0, bits_bytes, e->stream));
@@ -665,8 +667,9 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             HIP_TRY(hipStreamSynchronize(e->stream));
             const uint32_t n_det = (uint32_t)(h[2 * VJ_MAX_STAGES] & 0xffffffffull);
             const uint32_t n_tq = ((const uint32_t*)(h.data() + 2 * VJ_MAX_STAGES))[4 + 32];
-            if (tq_cap != 0u && n_tq > tq_cap) {   // more prefix survivors than the tree queue holds (a quarter of the windows): rows only
-                rows_only = true;
+            if (tq_cap != 0u && n_tq > tq_cap) {   // more prefix survivors than the tree queue holds
+                if (e->cv_tree_queue_cap > 0 || e->cv_tq_shift == 0) rows_only = true;
+                else e->cv_tq_shift = std::max(0, e->cv_tq_shift - 2);      // 1/16 -> 1/4 -> every window
                 --attempt;
                 continue;
             }

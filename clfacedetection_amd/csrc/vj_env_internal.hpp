@@ -249,6 +249,7 @@ struct vj_env {
     int cv_tile_ws_max = 512;     // ... windows a tile carries into its wave-split finish
     int cv_row_blocks = 3;        // ... workgroups per CU of cv_profile_pass while it runs next to the tiles (their LDS budget shrinks with it)
     int cv_row_blocks_tree = 2, cv_tile_min_windows_tree = 512;   // ... the same two for stage trees (swept: profiles/r03_cv_sweeps.log)
+    int cv_tq_shift = 4;              // ... stage trees: the survivors' queue holds 1 / 2^shift of the tile windows (grows on overflow)
     int cv_tree_queue_cap = 0;        // ... stage trees: capacity of the prefix survivors' queue (0: a quarter of the tile windows)
     int cv_tile_min_windows0 = 2048;   // ... the same for the class with two tile workgroups per CU
     int cv_tile_min_windows = 1536;   // ... a scale goes to tiles when a tile of at least this many windows fits the LDS
