@@ -2241,8 +2241,8 @@ int vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int n
         by_size[{r.w, r.h}].push_back(i);
     }
     // frames of one size, a linear cascade, the exhaustive grid: every region in one pass on the frames' own integral images
-    if (n_rois > 0 && n_frames > 0 && !(p->flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW)) && (p->scale_mask[0] | p->scale_mask[1]) == 0 &&
-        p->scale_factor > 1.0f && e->rois_on_device) {
+    // (a scale mask selects among the plan's scales; every region still enumerates its own prefix of them)
+    if (n_rois > 0 && n_frames > 0 && !(p->flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW)) && p->scale_factor > 1.0f && e->rois_on_device) {
         bool same = true;
         for (int i = 0; i < n_frames && same; ++i)
             same = frames[i].data && frames[i].width == frames[0].width && frames[i].height == frames[0].height &&
@@ -2313,8 +2313,8 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
         set_error("scale_factor must be > 1");
         return VJ_ERR_ARG;
     }
-    if ((p_first->flags | p_second->flags) & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW) || (p_second->scale_mask[0] | p_second->scale_mask[1]) != 0) {
-        set_error("vj_detect_chain: the skip modes and a scale mask on the second cascade are not supported");
+    if ((p_first->flags | p_second->flags) & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW)) {
+        set_error("vj_detect_chain: the skip modes are not supported");
         return VJ_ERR_UNSUPPORTED;
     }
     const bool grouped = p_first->min_neighbors != 0;   // the regions are the GROUPED candidates (grouped on the device)

@@ -305,11 +305,11 @@ int  vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, in
 /* A second cascade on regions of interest (BASELINE config 5: haarcascade_eye inside every face;
  * the reference's caller would hand clodDetectObjects a sub-image header: pointer + widthStep).
  * ROIs are views into `frames`.  In the result, rect.frame is the ROI's index and x / y are relative
- * to the ROI's origin.  Frames of one size with a linear cascade: the frames' integral images are
- * computed once and ALL regions, of whatever sizes, run in one pass on them (a rectangle sum does not
- * depend on where the integral image starts; vj_detect_chain's region pass with an uploaded list).
- * Otherwise (frames of different sizes, stage trees, skip modes, a scale mask): one vj_detect call per
- * region size on the sub-images.  Same result either way.                                        */
+ * to the ROI's origin.  Frames of one size: the frames' integral images are computed once and ALL
+ * regions, of whatever sizes, run in one pass on them (a rectangle sum does not depend on where the
+ * integral image starts; vj_detect_chain's region pass with an uploaded list; stage trees and scale
+ * masks included).  Otherwise (frames of different sizes, skip modes): one vj_detect call per region
+ * size on the sub-images.  Same result either way.                                               */
 typedef struct vj_roi { int32_t frame, x, y, w, h; } vj_roi;
 int  vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_frames,
                     const vj_roi* rois, int n_rois, const vj_params* p, vj_result* out);
@@ -323,7 +323,8 @@ int  vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int 
  * THE DEVICE (cv::groupRectangles per frame, as vj_detect groups them on the host: same classes, same
  * averages, same order) and the grouped faces are the regions.  out_first: as vj_detect with the same
  * parameters.  out_second: rect.frame = index of the region in out_first->rects, x / y relative to the
- * region's origin.  `second` may be any cascade of upright features (stumps, trees, stage trees).        */
+ * region's origin.  `second` may be any cascade of upright features (stumps, trees, stage trees);
+ * p_second->scale_mask selects scales by index as in vj_detect.  The skip modes are refused.              */
 int  vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second, const vj_image* frames,
                      int n_frames, const vj_params* p_first, const vj_params* p_second, vj_result* out_first,
                      vj_result* out_second);
