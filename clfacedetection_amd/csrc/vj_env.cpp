@@ -2314,8 +2314,18 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
         return VJ_ERR_ARG;
     }
     if ((p_first->flags | p_second->flags) & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW)) {
-        set_error("vj_detect_chain: the skip modes are not supported");
-        return VJ_ERR_UNSUPPORTED;
+        // the CPU variants' skip rules make a window's fate depend on its row's history inside ITS image: the first cascade runs
+        // as vj_detect does, the second one per region size on the sub-images (vj_detect_rois' path for these modes) — the
+        // hand-off goes through the host, the results are the ones the definition above gives
+        int rc = vj_detect(e, first, frames, n_frames, p_first, out_first);
+        if (rc) return rc;
+        std::vector<vj_roi> regions(out_first->count);
+        for (uint32_t i = 0; i < out_first->count; ++i) {
+            const vj_rect& q = out_first->rects[i];
+            regions[i] = vj_roi{(int32_t)q.frame, q.x, q.y, q.w, q.h};
+        }
+        if (regions.empty()) return VJ_OK;
+        return vj_detect_rois(e, second, frames, n_frames, regions.data(), (int)regions.size(), p_second, out_second);
     }
     const bool grouped = p_first->min_neighbors != 0;   // the regions are the GROUPED candidates (grouped on the device)
     int W, H, CH;

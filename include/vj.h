@@ -324,7 +324,8 @@ int  vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int 
  * averages, same order) and the grouped faces are the regions.  out_first: as vj_detect with the same
  * parameters.  out_second: rect.frame = index of the region in out_first->rects, x / y relative to the
  * region's origin.  `second` may be any cascade of upright features (stumps, trees, stage trees);
- * p_second->scale_mask selects scales by index as in vj_detect.  The skip modes are refused.              */
+ * p_second->scale_mask selects scales by index as in vj_detect.  With a skip mode (VJ_FLAG_SKIP_ROW / _LIST) on
+ * either cascade the hand-off goes through the host: vj_detect, then vj_detect_rois on the sub-images.     */
 int  vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second, const vj_image* frames,
                      int n_frames, const vj_params* p_first, const vj_params* p_second, vj_result* out_first,
                      vj_result* out_second);
