@@ -19,7 +19,7 @@ constexpr int PITCH = 149;          // dwords per tile row (s = 1 tile of 64 x 3
 constexpr int ROWS = 85;
 constexpr int TILE_DW = PITCH * ROWS;
 
-enum { FULL = 0, NOADD = 1, NOLDS = 2, NOALU = 3 };
+enum { FULL = 0, NOADD = 1, NOLDS = 2, NOALU = 3, ADDTID = 4 };   // ADDTID: dense rows only — ds_read_addtid_b32 (address = M0 + lane * 4), no VALU address adds
 
 template <int VAR>
 __global__ __launch_bounds__(512) void stump_loop(const Rec* table, uint32_t n_recs, uint32_t iters, uint32_t pattern, uint32_t keep_pm,
@@ -77,6 +77,24 @@ __global__ __launch_bounds__(512) void stump_loop(const Rec* table, uint32_t n_r
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
                 const uint32_t a[8] = {lt0, lt0 + dw0, lt0 + dh0, lt0 + dh0 + dw0, lt1, lt1 + dw1, lt1 + dh1, lt1 + dh1 + dw1};
+                if (VAR == ADDTID) {
+                    // the chunk is one tile row of 64 consecutive windows: lane l reads dword (row base + corner) / 4 + l
+                    const uint32_t rb = __builtin_amdgcn_readfirstlane(2u * (wib * 4u + (uint32_t)c) * PITCH * 4u);
+                    asm volatile(
+                        "s_add_u32 m0, %8, %9\n s_nop 0\n ds_read_addtid_b32 %0\n"
+                        "s_add_u32 m0, %8, %10\n s_nop 0\n ds_read_addtid_b32 %1\n"
+                        "s_add_u32 m0, %8, %11\n s_nop 0\n ds_read_addtid_b32 %2\n"
+                        "s_add_u32 m0, %8, %12\n s_nop 0\n ds_read_addtid_b32 %3\n"
+                        "s_add_u32 m0, %8, %13\n s_nop 0\n ds_read_addtid_b32 %4\n"
+                        "s_add_u32 m0, %8, %14\n s_nop 0\n ds_read_addtid_b32 %5\n"
+                        "s_add_u32 m0, %8, %15\n s_nop 0\n ds_read_addtid_b32 %6\n"
+                        "s_add_u32 m0, %8, %16\n s_nop 0\n ds_read_addtid_b32 %7\n"
+                        "s_waitcnt lgkmcnt(0)"
+                        : "=&v"(v[c][0]), "=&v"(v[c][1]), "=&v"(v[c][2]), "=&v"(v[c][3]), "=&v"(v[c][4]), "=&v"(v[c][5]), "=&v"(v[c][6]), "=&v"(v[c][7])
+                        : "s"(rb), "s"(a[0]), "s"(a[1]), "s"(a[2]), "s"(a[3]), "s"(a[4]), "s"(a[5]), "s"(a[6]), "s"(a[7])
+                        : "m0", "memory");
+                    continue;
+                }
 #pragma unroll
                 for (int k = 0; k < 8; ++k) {
                     if (VAR == NOLDS) v[c][k] = off[c] ^ a[k];
@@ -154,16 +172,18 @@ int main() {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const size_t lds_bytes = (size_t)TILE_DW * 4 + 16384;   // image + what the queues take in the real kernel
-    const void* fns[] = {(const void*)stump_loop<FULL>, (const void*)stump_loop<NOADD>, (const void*)stump_loop<NOLDS>, (const void*)stump_loop<NOALU>};
+    const void* fns[] = {(const void*)stump_loop<FULL>, (const void*)stump_loop<NOADD>, (const void*)stump_loop<NOLDS>, (const void*)stump_loop<NOALU>,
+                         (const void*)stump_loop<ADDTID>};
     for (const void* f : fns) hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     struct Pat { const char* name; uint32_t pattern, keep; };
     const Pat pats[] = {{"dense rows (stage 0)", 0, 0}, {"survivors p=0.67 in order", 1, 670}, {"survivors p=0.30 in order", 1, 300},
                         {"survivors p=0.10 in order", 1, 100}, {"unrelated windows", 2, 0}, {"survivors p=0.30 binned", 3, 300},
                         {"survivors p=0.10 binned", 3, 100}, {"survivors p=0.03 binned", 3, 30}};
-    const char* vnames[] = {"full", "no address adds", "no LDS reads", "no arithmetic"};
+    const char* vnames[] = {"full", "no address adds", "no LDS reads", "no arithmetic", "addtid reads"};
     for (int wg_per_cu : {1, 2}) {
         for (const Pat& pt : pats) {
-            for (int var = 0; var < 4; ++var) {
+            for (int var = 0; var < 5; ++var) {
+                if (var == 4 && pt.pattern != 0) continue;   // addtid reads need consecutive windows in the lanes
                 const uint32_t iters = 40;
                 const int blocks = cus * wg_per_cu;
                 if (pt.pattern == 3) {
@@ -175,7 +195,8 @@ int main() {
                         case 0: hipLaunchKernelGGL(stump_loop<FULL>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out, d_binned); break;
                         case 1: hipLaunchKernelGGL(stump_loop<NOADD>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out, d_binned); break;
                         case 2: hipLaunchKernelGGL(stump_loop<NOLDS>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out, d_binned); break;
-                        default: hipLaunchKernelGGL(stump_loop<NOALU>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out, d_binned); break;
+                        case 3: hipLaunchKernelGGL(stump_loop<NOALU>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out, d_binned); break;
+                        default: hipLaunchKernelGGL(stump_loop<ADDTID>, dim3(blocks), dim3(512), lds_bytes, 0, d_tab, n_recs, iters, pt.pattern, pt.keep, d_out, d_binned); break;
                     }
                 };
                 run();
