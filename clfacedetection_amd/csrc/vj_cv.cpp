@@ -450,7 +450,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
         if ((rc = enqueue_integral(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf, CH))) return rc;
         if (has_tilted && (rc = enqueue_tilted(e, d_gray, gray_frame_bytes, gray_stride, W, H, nf, CH))) return rc;
         HIP_TRY(hipEventRecord(e->lane0.ev[1], e->stream));
-        bool rows_only = false;
+        bool rows_only = false, done = false;
         for (int attempt = 0; attempt < 2; ++attempt) {
             if ((rc = d_det.ensure((size_t)det_cap * sizeof(CvDet)))) return rc;
             HIP_TRY(hipMemsetAsync(d_counts.p, 0, counts_bytes, e->stream));
@@ -694,7 +694,12 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             for (const CvDet& d : raw)
                 all.push_back(vj_rect{(int32_t)d.x, (int32_t)d.y, (int32_t)scales[d.slot].win_w, (int32_t)scales[d.slot].win_h,
                                       0.0f, f0 + (int32_t)d.frame, (int32_t)scales[d.slot].scale_idx});
+            done = true;
             break;
+        }
+        if (!done) {   // (cannot happen: the counts of a repeated pass are the counts that sized its buffers)
+            set_error("vj_detect_opencv: the detection buffer overflowed twice");
+            return VJ_ERR_LIMIT;
         }
     }
     std::sort(all.begin(), all.end(), [](const vj_rect& a, const vj_rect& b) {

@@ -582,7 +582,7 @@ static vj_env::Balance* balance_of(vj_env* e, const vj_cascade* c, int W, int H,
     if (!create) return nullptr;
     if (e->balance.size() > 256) e->balance.clear();   // bounded
     vj_env::Balance b;
-    b.cur = b.best = e->split_for(n_frames);
+    b.cur = b.best = e->split_for(n_frames, p);
     return &(e->balance[key] = b);
 }
 
@@ -626,7 +626,7 @@ static void balance_report(vj_env::Balance* b, float ms) {
 
 static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, Plan** out, int n_frames = 1 << 20) {
     const vj_env::Balance* bal = balance_of(e, c, W, H, p, n_frames, false);
-    const float split = bal ? bal->cur : e->split_for(n_frames);
+    const float split = bal ? bal->cur : e->split_for(n_frames, p);
     const int small = small_frame_class(e, W, H, n_frames);
     vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
                         p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64)) | ((uint32_t)small << 8), f2u(split));
@@ -2214,11 +2214,19 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
         rc = detect_subbatch(e, pl, frames, f0, nf, W, H, *p, &dets, &out->counters, &out->timing);
         if (rc) return rc;
     }
-    // feedback for the chain balance: only plans that run two chains, only the timed (uncounted) kernel variants
-    if (bal && pl->block_first > 0 && !pl->units.empty() && !(p->flags & VJ_FLAG_COUNTERS) && (uint64_t)n_frames <= max_frames)
-        balance_report(bal, out->timing.cascade_ms);
-    else if (bal && bal->phase != 3 && (pl->block_first == 0 || pl->units.empty()))
-        bal->phase = 3;      // one chain only: nothing to balance
+    // feedback for the chain balance: only the timed (uncounted) kernel variants.  A plan none of whose scales can run on tiles
+    // has nothing to balance; a CANDIDATE split that leaves one chain only (every tile moved to the gathers, or a share of
+    // the scales without large ones) is measured like any other — the search must be able to step back from it
+    if (bal && bal->phase != 3) {
+        bool any_tile_scale = false;
+        for (const ScaleDev& sd : pl->scales) any_tile_scale |= sd.tile_rw != 0;
+        if (!any_tile_scale) {
+            bal->cur = bal->best;
+            bal->phase = 3;
+        } else if (!(p->flags & VJ_FLAG_COUNTERS) && (uint64_t)n_frames <= max_frames) {
+            balance_report(bal, out->timing.cascade_ms);
+        }
+    }
     out->timing.tile_split = pl->tile_split;
     return build_result(pl, dets, n_frames, *p, out);
 }
@@ -2620,7 +2628,7 @@ int vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int 
     } guard{nullptr};
     // (a chain balance already found for this workload by vj_detect's feedback is taken over; a stream does not search itself)
     const vj_env::Balance* bal = balance_of(e, c, width, height, *p, max_batch, false);
-    int rc = build_plan(e, *c, width, height, *p, s->plan.get(), bal ? bal->best : e->split_for(max_batch),
+    int rc = build_plan(e, *c, width, height, *p, s->plan.get(), bal ? bal->best : e->split_for(max_batch, *p),
                         TileThresholds{e->tile_min_windows, e->tile_accept_windows, e->tile_max_dwords_per_window});
     if (rc) {
         s->plan->release_device();

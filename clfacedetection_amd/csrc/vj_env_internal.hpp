@@ -175,6 +175,11 @@ struct vj_env {
     float tile_split_mid = 0.5f;        // 5 .. 31 frames
     float tile_split_small = 0.0f;      // <= 4 frames
     float split_for(int n_frames) const { return n_frames <= 4 ? tile_split_small : n_frames < 32 ? tile_split_mid : tile_split; }
+    // (the defaults are fractions of the last tile scale of a WHOLE pyramid; a share of the scales (vj_shard_scales) may end with a
+    // scale of half a million windows: it starts without a move and lets the feedback find one)
+    float split_for(int n_frames, const vj_params& p) const {
+        return ((p.scale_mask[0] | p.scale_mask[1]) != 0 && !tile_split_set) ? 0.0f : split_for(n_frames);
+    }
     int xcd_affinity = 1;               // global-gather first pass: one contiguous part of the work per XCD (L2 locality)
     int tile_segments = 1;              // stage trees: tiles run the chains after the prefix themselves
     int seg_cut2 = 0;                   // stage trees: a second cut inside a long chain after this many of its stages (0: none)

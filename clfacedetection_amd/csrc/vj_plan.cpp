@@ -205,23 +205,40 @@ int vj_shard_scales(const vj_cascade* c, int width, int height, const vj_params*
         set_error("more than 127 scales cannot be expressed as a scale mask");
         return VJ_ERR_LIMIT;
     }
+    // Estimated cost of a scale = windows x a per-window weight (1/16 units, integers only so that every host computes the same
+    // shares).  Scales whose window is at most 72 px run on LDS tiles (weight 16 at s = 1, rising with the staged footprint per
+    // window); larger ones are global gathers, about six times as expensive per window and rising with the window (measured per
+    // scale: profiles/r03_notes.md #7).  The two kinds run as two overlapping chains on a device, so they are dealt separately:
+    // every rank gets its part of BOTH — tiles to the rank with the least tile cost, gathers to the rank with the least
+    // (gather cost + half its tile cost): equal gather shares where the tile shares are equal, more gathers where a rank got fewer tiles.
+    const uint64_t base = (uint64_t)std::max(c->win_w, c->win_h);
     std::vector<uint64_t> w(sc.size());
+    std::vector<int> gather(sc.size());
     std::vector<size_t> order(sc.size());
     for (size_t k = 0; k < sc.size(); ++k) {
-        w[k] = sc[k].accepted ? (uint64_t)sc[k].nx * (uint64_t)sc[k].ny : 0;
+        const uint64_t side = (uint64_t)std::max(sc[k].win_w, sc[k].win_h);
+        const uint64_t q = std::max<uint64_t>(16u, side * 16u / std::max<uint64_t>(base, 1u));   // scale factor in 1/16
+        gather[k] = side > 72u;
+        const uint64_t weight = gather[k] ? 96u + 13u * (std::max<uint64_t>(q, 61u) - 61u) / 16u : 16u + 10u * (q - 16u) / 16u;
+        w[k] = sc[k].accepted ? (uint64_t)sc[k].nx * (uint64_t)sc[k].ny * weight : 0;
         order[k] = k;
     }
-    // longest processing time first; equal counts keep their scale order
+    // longest processing time first; equal costs keep their scale order
     std::stable_sort(order.begin(), order.end(), [&](size_t a, size_t b) { return w[a] > w[b]; });
-    std::vector<uint64_t> load((size_t)n_ranks, 0);
+    std::vector<uint64_t> tile((size_t)n_ranks, 0), gath((size_t)n_ranks, 0);
+    auto est = [](uint64_t t, uint64_t g) { return g + t / 2u; };
     scale_mask[0] = scale_mask[1] = 0;
-    for (size_t k : order) {
-        size_t r = 0;
-        for (size_t i = 1; i < load.size(); ++i)
-            if (load[i] < load[r]) r = i;
-        load[r] += w[k];
-        if ((int)r == rank) scale_mask[k >> 6] |= 1ull << (k & 63);
-    }
+    for (int cls = 0; cls < 2; ++cls)
+        for (size_t k : order) {
+            if (gather[k] != cls) continue;
+            size_t r = 0;
+            for (size_t i = 1; i < (size_t)n_ranks; ++i) {
+                const bool less = cls == 0 ? tile[i] < tile[r] : est(tile[i], gath[i] + w[k]) < est(tile[r], gath[r] + w[k]);
+                if (less) r = i;
+            }
+            (cls == 0 ? tile[r] : gath[r]) += w[k];
+            if ((int)r == rank) scale_mask[k >> 6] |= 1ull << (k & 63);
+        }
     // an all-zero mask means "every scale" to vj_detect: a rank without a share says so explicitly
     if ((scale_mask[0] | scale_mask[1]) == 0) scale_mask[1] = VJ_SCALE_MASK_NONE;
     return VJ_OK;

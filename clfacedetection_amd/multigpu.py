@@ -5,8 +5,9 @@ independent given that frame's integral images.  So
   * a batch with at least as many frames as ranks is split by whole frames
     (contiguous blocks, so each rank integrates only its own frames);
   * fewer frames than ranks (e.g. one 4096x4096 frame): every rank takes all frames
-    but only a subset of the scales, balanced by window count with the
-    longest-processing-time greedy rule;
+    but only a subset of the scales, balanced by estimated cost (window count x a
+    per-window weight for the LDS-tile and the global-gather scales, each kind dealt
+    longest-first so that every rank keeps both of its chains busy);
 and the only collective is the final all-gather of the detection rectangles
 (torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
 tests).  Payloads are a few KB, so this is latency-, not bandwidth-bound.
@@ -27,25 +28,49 @@ def shard_frames(n_frames: int, rank: int, world: int) -> range:
     return range(lo, lo + base + (1 if rank < extra else 0))
 
 
-def shard_scales(window_counts: list[int], rank: int, world: int) -> list[int]:
-    """LPT-greedy assignment of scale indices to ranks, by candidate-window count
-    (very skewed: 503,500 ... 38 at 1080p).  Deterministic: ties go to the lower rank."""
-    order = sorted(range(len(window_counts)), key=lambda k: (-window_counts[k], k))
-    load = [0] * world
+def shard_scales(window_counts: list[int], rank: int, world: int, window_sides: list[int] | None = None,
+                 base_side: int = 0) -> list[int]:
+    """vj_shard_scales' rule (csrc/vj_plan.cpp), integer arithmetic throughout so that every host computes the same shares:
+    a scale costs windows x a per-window weight — scales whose window is at most 72 px run on LDS tiles (weight 16/16 at s = 1,
+    rising with the staged footprint), larger ones are global gathers (about six times as much per window) — and the two
+    kinds, which run as two overlapping chains on a device, are dealt separately, longest first: tiles to the rank with the
+    least tile cost, gathers to the rank with the least (gather cost + half its tile cost).
+    Ties go to the lower rank.  Without `window_sides` (the scaled window's larger side per scale; `base_side` = the
+    cascade's own) every scale weighs the same: plain LPT on the window counts."""
+    n = len(window_counts)
+    gather = [0] * n
+    cost = [16 * int(w) for w in window_counts]
+    if window_sides is not None:
+        for k in range(n):
+            side = int(window_sides[k])
+            q = max(16, side * 16 // max(int(base_side), 1))
+            gather[k] = 1 if side > 72 else 0
+            weight = 96 + 13 * (max(q, 61) - 61) // 16 if gather[k] else 16 + 10 * (q - 16) // 16
+            cost[k] = int(window_counts[k]) * weight
+    order = sorted(range(n), key=lambda k: (-cost[k], k))
+    tile, gath = [0] * world, [0] * world
+    est = lambda t, g: g + t // 2
     mine = []
-    for k in order:
-        r = min(range(world), key=lambda i: (load[i], i))
-        load[r] += window_counts[k]
-        if r == rank:
-            mine.append(k)
+    for cls in (0, 1):
+        for k in order:
+            if gather[k] != cls:
+                continue
+            if cls == 0:
+                r = min(range(world), key=lambda i: (tile[i], i))
+                tile[r] += cost[k]
+            else:
+                r = min(range(world), key=lambda i: (est(tile[i], gath[i] + cost[k]), i))
+                gath[r] += cost[k]
+            if r == rank:
+                mine.append(k)
     return sorted(mine)
 
 
-def plan(n_frames: int, window_counts: list[int], rank: int, world: int):
+def plan(n_frames: int, window_counts: list[int], rank: int, world: int, window_sides: list[int] | None = None, base_side: int = 0):
     """-> (frame indices, scale indices or None for all scales) for this rank."""
     if world == 1 or n_frames >= world:
         return list(shard_frames(n_frames, rank, world)), None
-    return list(range(n_frames)), shard_scales(window_counts, rank, world)
+    return list(range(n_frames)), shard_scales(window_counts, rank, world, window_sides, base_side)
 
 
 def allgather_rects(rects: np.ndarray, device=None, group=None) -> np.ndarray:

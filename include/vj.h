@@ -358,8 +358,9 @@ int vj_group_rectangles(vj_rect* rects, uint32_t* count, int group_threshold, do
  * does not link librccl).
  * vj_shard_frames: batches with at least as many frames as ranks — contiguous blocks whose sizes differ by at most one.
  * vj_shard_scales: fewer frames than ranks (one large frame) — every rank integrates the frame and takes a subset of the
- * scales, longest-processing-time greedy on the window counts (ties to the lower rank); the result goes into
- * vj_params.scale_mask.  A rank that gets no scale (more ranks than scales) receives VJ_SCALE_MASK_NONE — an all-zero
+ * scales, longest-processing-time greedy on an estimated cost (windows x a per-window weight; the LDS-tile scales and the
+ * global-gather scales are dealt separately so that each rank keeps both of its chains busy; integers only, ties to the
+ * lower rank); the result goes into vj_params.scale_mask.  A rank that gets no scale (more ranks than scales) receives VJ_SCALE_MASK_NONE — an all-zero
  * mask would mean "every scale" and duplicate the other ranks' rectangles.                                                                                            */
 int vj_shard_frames(int n_frames, int n_ranks, int rank, int* first, int* count);
 int vj_shard_scales(const vj_cascade* c, int width, int height, const vj_params* p, int n_ranks, int rank,

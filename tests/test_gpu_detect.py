@@ -517,3 +517,25 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
         assert np.array_equal(env.detect(c, frames).rects, first.rects)
     finally:
         env.configure("auto_balance", "reset")
+    # a pyramid with ONE tile scale (frontalface_alt, min size 66: the 69-px scale runs on tiles, everything above on gathers) and
+    # a search that starts with that scale moved to the gather chain: a one-chain plan.  The search measures it like any other
+    # candidate and goes on (up, then back below the start) — it used to end on such a plan, whatever it cost.
+    alt, _ = cascades("frontalface_alt")
+    env.configure("tile_split", "1.0")
+    env.configure("auto_balance", "reset")               # feedback on again, the start values stay
+    try:
+        p = default_params(min_w=66, min_h=66)
+        ref = env.detect(alt, frames, p)
+        assert ref.tile_split == 1.0 and not any(l["kind"] == "tile" for l in ref.launches)
+        seen = []
+        for _ in range(40):
+            r = env.detect(alt, frames, p)
+            assert np.array_equal(r.rects, ref.rects)
+            seen.append(r.tile_split)
+        assert len(set(seen[-6:])) == 1 and len(set(seen)) >= 3, seen
+    finally:
+        env.configure("tile_split", "0,0.5,0.5")
+        env.configure("auto_balance", "reset")
+    # a share of the scales (a mask) starts without a move: the default is a fraction of the last tile scale of a WHOLE pyramid
+    assert env.detect(c, frames, default_params(scales=[0, 1, 20, 21])).tile_split == 0.0
+    env.configure("auto_balance", "reset")

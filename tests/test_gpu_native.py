@@ -68,7 +68,8 @@ def _rank(rank, world, port, mode, q):
     n_frames = 5 if mode == "frames" else 1
     frames = synth.batch(n_frames, H, W, seed0=900, kinds=("noise", "blocks"))
     counts = [s.nx * s.ny if s.accepted else 0 for s in c.plan_scales(W, H)]
-    my_frames, my_scales = multigpu.plan(n_frames, counts, rank, world)
+    sides = [max(s.win_w, s.win_h) for s in c.plan_scales(W, H)]
+    my_frames, my_scales = multigpu.plan(n_frames, counts, rank, world, sides, max(c.info.win_w, c.info.win_h))
     if my_scales is not None:
         assert my_scales == c.shard_scales(W, H, rank, world)          # the native helper picks the same scales
     p = default_params(scales=my_scales) if my_scales is not None else default_params()

@@ -48,10 +48,15 @@ def test_native_shard_helpers_agree_with_the_python_ones(lib, cascades):
     for name, (w, h) in (("frontalface_alt", (1920, 1080)), ("frontalface_alt_tree", (4096, 4096)), ("eye", (300, 200))):
         c, _ = cascades(name)
         counts = [s.nx * s.ny if s.accepted else 0 for s in c.plan_scales(w, h)]
+        sides = [max(s.win_w, s.win_h) for s in c.plan_scales(w, h)]
+        base = max(c.info.win_w, c.info.win_h)
         for world in (1, 2, 4, 8):
             parts = [c.shard_scales(w, h, r, world) for r in range(world)]
-            assert parts == [multigpu.shard_scales(counts, r, world) for r in range(world)]
+            assert parts == [multigpu.shard_scales(counts, r, world, sides, base) for r in range(world)]
             assert sorted(k for p in parts for k in p) == list(range(len(counts)))
+            if world > 1 and name != "eye":      # every rank gets LDS-tile scales AND global-gather scales: both of its chains have work
+                for p in parts:
+                    assert any(sides[k] <= 72 for k in p) and any(sides[k] > 72 for k in p), (name, world, p)
 
 
 def test_a_rank_without_a_share_gets_the_explicit_empty_mask(lib, cascades):
