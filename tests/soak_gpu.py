@@ -113,22 +113,30 @@ while time.time() < t_end:
                 rw_, rh_ = int(rng.integers(c.info.win_w + 11, max(c.info.win_w + 12, min(w, 260)))), int(rng.integers(c.info.win_h + 11, max(c.info.win_h + 12, min(h, 260))))
                 rw_, rh_ = min(rw_, w), min(rh_, h)
                 rois.append((int(rng.integers(0, len(imgs))), int(rng.integers(0, w - rw_ + 1)), int(rng.integers(0, h - rh_ + 1)), rw_, rh_))
-            r = env.detect_rois(c, imgs, rois, default_params(flags=VJ_FLAG_COUNTERS))
+            keep = None
+            if rng.random() < 0.3:                # a scale mask: the region pass evaluates the selected scales only
+                keep = [k for k in range(40) if rng.random() < 0.6] or [0]
+            pr = default_params(flags=VJ_FLAG_COUNTERS) if keep is None else default_params(flags=VJ_FLAG_COUNTERS, scales=keep)
+            r = env.detect_rois(c, imgs, rois, pr)
             entered = np.zeros(len(r.stage_entered), np.int64)
             for i, (f, x, y, ww, hh) in enumerate(rois):
                 ro, st = o.detect(a, np.ascontiguousarray(imgs[f][y:y + hh, x:x + ww]))
-                ok &= rows(r.rects[r.rects["frame"] == i]) == rows(ro)
+                want = rows(ro) if keep is None else [q for q in rows(ro) if q[0] in keep]
+                ok &= rows(r.rects[r.rects["frame"] == i]) == want
                 entered += np.array(st["stage_entered"], np.int64)
-            ok &= r.stage_entered == entered.tolist()
-            desc += (rois,)
+            if keep is None:
+                ok &= r.stage_entered == entered.tolist()
+            desc += (rois, keep)
         else:
             if not linear or name == "eye":
                 name = "frontalface_alt2"
                 c, a = CASC[name]
             c2, a2 = CASC["eye"]
             mnb = 0 if mode == "chain" else int(rng.integers(1, 4))
-            r1, r2 = env.detect_chain(c, c2, [img] * nb if nb > 1 else img, default_params(min_neighbors=mnb))
-            ro, _ = o.detect(a, img)
+            skip = int(rng.integers(0, 6)) if mode == "chain" else 0      # 1: row skip rule, 2: list skip rule on both cascades (host hand-off)
+            flag1, omode = {1: (VJ_FLAG_SKIP_ROW, 3), 2: (VJ_FLAG_SKIP_LIST, 2)}.get(skip, (0, None))
+            r1, r2 = env.detect_chain(c, c2, [img] * nb if nb > 1 else img, default_params(min_neighbors=mnb, flags=flag1), default_params(flags=flag1))
+            ro, _ = o.detect(a, img, mode=omode)
             if mnb:
                 xywh = np.stack([ro[k] for k in ("x", "y", "w", "h")], 1) if len(ro) else np.zeros((0, 4), np.int32)
                 g, wt = o.group_rectangles(xywh, mnb)
@@ -139,9 +147,9 @@ while time.time() < t_end:
                 got1 = [(int(q["x"]), int(q["y"]), int(q["w"]), int(q["h"]), 0) for q in r1.rects[r1.rects["frame"] == 0]]
             ok &= got1 == want1
             for i, (x, y, ww, hh, _) in enumerate(want1[:6]):
-                r2o, _ = o.detect(a2, np.ascontiguousarray(img[y:y + hh, x:x + ww]))
+                r2o, _ = o.detect(a2, np.ascontiguousarray(img[y:y + hh, x:x + ww]), mode=omode)
                 ok &= rows(r2.rects[r2.rects["frame"] == i]) == rows(r2o)
-            desc += (mnb, len(want1))
+            desc += (mnb, len(want1), skip)
     except Exception as e:   # noqa: BLE001
         ok = False
         desc += (repr(e),)
