@@ -587,7 +587,7 @@ static vj_env::Balance* balance_of(vj_env* e, const vj_cascade* c, int W, int H,
 }
 
 // One more measured call (cascade kernels' time, uncounted variants) of a workload that is still being balanced.  Three
-// calls per candidate, the first of which pays for the plan: the fastest counts.  Steps of half a scale; a move needs 0.7 %.
+// calls per candidate, the first of which pays for the plan: the fastest counts.  Steps of a quarter of a scale; a move needs 0.7 %.
 static void balance_report(vj_env::Balance* b, float ms) {
     if (!b || b->phase == 3 || !(ms > 0.0f)) return;
     ++b->calls;
@@ -598,7 +598,7 @@ static void balance_report(vj_env::Balance* b, float ms) {
     b->cand_ms = std::min(b->cand_ms, ms);
     if (b->samples < 3) return;
     b->samples = 0;
-    const float step = 0.5f, max_split = 3.0f;
+    const float step = 0.25f, max_split = 3.0f;
     auto freeze = [&]() { b->cur = b->best; b->phase = 3; };
     if (b->phase == 0) {
         b->best_ms = b->cand_ms;
@@ -614,7 +614,7 @@ static void balance_report(vj_env::Balance* b, float ms) {
         b->best_ms = b->cand_ms;
         b->moved = 1;
         const float next = b->phase == 1 ? b->cur + step : b->cur - step;
-        if (next < 0.0f || next > max_split || b->calls > 40) freeze();
+        if (next < 0.0f || next > max_split || b->calls > 60) freeze();
         else b->cur = next;
     } else if (b->phase == 1 && !b->moved && b->best >= step) {
         b->phase = 2;

@@ -171,8 +171,8 @@ struct vj_env {
     // frame is bound by the latency of the gather chain's thin queue pass (measured, 1080p / frontalface_alt: 1 frame
     // 1.20 / 1.46 / 1.46 ms at split 0 / 0.5 / 1.25; 4 frames 3.50 / 3.61 / 3.96; 16 frames 12.51 / 12.25 / 12.36;
     // 64 frames — / 48.0 / 54.0), so small batches keep everything they can on the tiles
-    float tile_split = 0.5f;            // batches of >= 32 frames (with gather_pairs = 2, 1.25 is as good: 48.1 vs 48.0 ms)
-    float tile_split_mid = 0.5f;        // 5 .. 31 frames
+    float tile_split = 0.75f;           // batches of >= 32 frames (64 x 1080p: 47.68 / 47.27 / 46.90 / 46.68 / 47.55 ms for 0.25 / 0.5 / 0.625 / 0.75 / 1; 32: 23.95 / 23.70 / 23.39 / 23.86)
+    float tile_split_mid = 0.5f;        // 5 .. 31 frames (8 x 1080p: 6.14 / 6.06 / 6.03 / 6.10 / 6.33 ms for 0 / 0.25 / 0.5 / 0.75 / 1)
     float tile_split_small = 0.0f;      // <= 4 frames
     float split_for(int n_frames) const { return n_frames <= 4 ? tile_split_small : n_frames < 32 ? tile_split_mid : tile_split; }
     // (the defaults are fractions of the last tile scale of a WHOLE pyramid; a share of the scales (vj_shard_scales) may end with a
