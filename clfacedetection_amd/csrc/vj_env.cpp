@@ -49,9 +49,10 @@ static std::vector<uint32_t> default_pass_bounds(const vj_cascade& c, const Stag
         for (int v : override_)
             if (v > (int)b.back() && v < (int)n) b.push_back((uint32_t)v);
     } else {
-        // cuts after given numbers of cumulative nodes (default: one, after ~150 — frontalface_alt: before stage 6 —
-        // measured best on 1080p batches: [0,6) global first pass, one re-packed queue pass for the rest, both on
-        // the global-gather chain while the tile chain runs the whole cascade next to it)
+        // cuts after given numbers of cumulative nodes (default: one, after 35 — frontalface_alt: before stage 3 —
+        // measured best on batches of four cascades: [0,3) global first pass, one queue pass for the rest whose chunks hold
+        // the survivors of the whole batch re-packed, both on the global-gather chain while the tile chain runs the whole
+        // cascade next to it; round 1 cut after ~150 nodes, which the frame-major chunk order of round 3 made too late)
         uint32_t acc = 0;
         size_t ci = 0;
         for (uint32_t s = 0; s < n && ci < cut_nodes.size(); ++s) {

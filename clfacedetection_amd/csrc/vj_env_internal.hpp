@@ -270,7 +270,7 @@ struct vj_env {
                                   // only takes issue slots from the tile chain: 64 x 1080p 47.98 / 48.21 / 49.21 ms for 0 / 1 / 2)
     uint32_t pairs_for(int n_frames) const { return gather_pairs >= 0 ? (uint32_t)gather_pairs : n_frames <= 4 ? 2u : 0u; }
     std::vector<int> split_override;
-    std::vector<int> pass_cut_nodes{150};   // default pass cuts, in cumulative nodes
+    std::vector<int> pass_cut_nodes{35};    // default pass cuts, in cumulative nodes (profiles/r03_notes.md #6c: 35 beats 150 on four cascades)
 };
 
 namespace vj {
