@@ -2342,6 +2342,8 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
     Plan *pl1, *pl2;
+    // (the first cascade's chain balance is found by feedback as in vj_detect: its kernels run before the region pass starts)
+    vj_env::Balance* bal = balance_of(e, first, W, H, *p_first, n_frames, true);
     if ((rc = get_plan(e, first, W, H, *p_first, &pl1, n_frames))) return rc;
     // the second cascade is planned for the frame's stride and every scale a region as large as the frame could use;
     // each region picks its own scales and grid on the device
@@ -2532,6 +2534,17 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
             for (size_t s2 = 0; s2 < pl2->stages.size(); ++s2) out_second->counters.stage_entered[s2] += se[s2];
         }
     }
+    if (bal && bal->phase != 3) {   // (as vj_detect: one sub-batch, timed kernel variants only)
+        bool any_tile_scale = false;
+        for (const ScaleDev& sd : pl1->scales) any_tile_scale |= sd.tile_rw != 0;
+        if (!any_tile_scale) {
+            bal->cur = bal->best;
+            bal->phase = 3;
+        } else if (!(p_first->flags & VJ_FLAG_COUNTERS) && (uint64_t)n_frames <= max_frames) {
+            balance_report(bal, out_first->timing.cascade_ms);
+        }
+    }
+    out_first->timing.tile_split = pl1->tile_split;
     // the first result in its sorted order; regions are numbered by their position in it
     std::vector<uint32_t> rank;
     if (grouped) {   // frames in order, groups in cv::partition's class order: already the result's order

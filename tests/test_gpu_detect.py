@@ -536,6 +536,15 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
     finally:
         env.configure("tile_split", "0,0.5,0.75")
         env.configure("auto_balance", "reset")
+    # vj_detect_chain searches the balance of its first cascade the same way: same two results in every call of the search
+    eye, _ = cascades("eye")
+    c1, c2 = env.detect_chain(c, eye, frames)
+    seen = []
+    for _ in range(30):
+        r1, r2 = env.detect_chain(c, eye, frames)
+        assert np.array_equal(r1.rects, c1.rects) and np.array_equal(r2.rects, c2.rects)
+        seen.append(r1.tile_split)
+    assert len(set(seen[-6:])) == 1 and len(set(seen)) >= 2, seen
     # a share of the scales (a mask) starts without a move: the default is a fraction of the last tile scale of a WHOLE pyramid
     assert env.detect(c, frames, default_params(scales=[0, 1, 20, 21])).tile_split == 0.0
     env.configure("auto_balance", "reset")
