@@ -574,7 +574,10 @@ static int small_frame_class(const vj_env* e, int W, int H, int n_frames) {
 
 // The workload whose chain balance is being found (or was found) by feedback: batches of >= 8 frames through vj_detect.
 static vj_env::Balance* balance_of(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, int n_frames, bool create) {
-    if (!e->auto_balance || e->tile_split_set || !e->concurrent || n_frames < 8 || n_frames >= (1 << 20)) return nullptr;
+    // (calls of at least eight frames or sixteen megapixels: below that a call is a millisecond and its time says little)
+    if (!e->auto_balance || e->tile_split_set || !e->concurrent || n_frames >= (1 << 20) ||
+        (n_frames < 8 && (uint64_t)W * (uint64_t)H * (uint64_t)n_frames < 16000000ull))
+        return nullptr;
     const vj_env::BalanceKey key(vj_env::PlanKey(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
                                                  p.scale_mask[1], p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64), 0u),
                                  n_frames);
@@ -589,7 +592,7 @@ static vj_env::Balance* balance_of(vj_env* e, const vj_cascade* c, int W, int H,
 
 // One more measured call (cascade kernels' time, uncounted variants) of a workload that is still being balanced.  Three
 // calls per candidate, the first of which pays for the plan: the fastest counts.  Steps of a quarter of a scale; a move needs 0.7 %.
-static void balance_report(vj_env::Balance* b, float ms) {
+static void balance_report(vj_env::Balance* b, float ms, bool try_thresholds) {
     if (!b || b->phase == 3 || !(ms > 0.0f)) return;
     ++b->calls;
     if (++b->samples == 1) {
@@ -600,7 +603,43 @@ static void balance_report(vj_env::Balance* b, float ms) {
     if (b->samples < 3) return;
     b->samples = 0;
     const float step = 0.25f, max_split = 3.0f;
-    auto freeze = [&]() { b->cur = b->best; b->phase = 3; };
+    // the split is settled: one more candidate — the same split with the lower tile thresholds (how many scales the tile chain
+    // can take at all: the better value depends on the frames' content, profiles/r03_notes.md #6e) — then the search ends
+    // — and before that one probe a whole scale further: the response is not always convex (a scale split between the two
+    // chains can cost more than the same scale moved entirely), and a climb in quarters stops at the first rise
+    auto freeze = [&]() {
+        b->cur = b->best;
+        if (!b->far_tried && b->best + 1.0f <= max_split && b->calls <= 60) {
+            b->far_tried = true;
+            b->cur = b->best + 1.0f;
+            b->phase = 5;
+        } else if (try_thresholds && !b->thr_tried) {
+            b->thr_tried = true;
+            b->thr = 1;
+            b->phase = 4;
+        } else {
+            b->phase = 3;
+        }
+    };
+    if (b->phase == 4) {
+        if (b->cand_ms < b->best_ms * 0.993f) b->best_ms = b->cand_ms;
+        else b->thr = 0;
+        b->phase = 3;
+        return;
+    }
+    if (b->phase == 5) {
+        if (b->cand_ms < b->best_ms * 0.993f) {   // the far side is better: climb on from there
+            b->best = b->cur;
+            b->best_ms = b->cand_ms;
+            b->moved = 0;
+            b->phase = 1;
+            if (b->best + step <= max_split) b->cur = b->best + step;
+            else { b->phase = 2; b->cur = b->best - step; }
+        } else {
+            freeze();
+        }
+        return;
+    }
     if (b->phase == 0) {
         b->best_ms = b->cand_ms;
         b->phase = 1;
@@ -628,7 +667,8 @@ static void balance_report(vj_env::Balance* b, float ms) {
 static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, Plan** out, int n_frames = 1 << 20) {
     const vj_env::Balance* bal = balance_of(e, c, W, H, p, n_frames, false);
     const float split = bal ? bal->cur : e->split_for(n_frames, p);
-    const int small = small_frame_class(e, W, H, n_frames);
+    int small = small_frame_class(e, W, H, n_frames);
+    if (small == 0 && bal && bal->thr == 1 && !e->tile_thresholds_set) small = 3;   // the feedback's lower thresholds
     vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
                         p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64)) | ((uint32_t)small << 8), f2u(split));
     auto it = e->plans.find(key);
@@ -653,6 +693,7 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
     TileThresholds th{e->tile_min_windows, e->tile_accept_windows, e->tile_max_dwords_per_window};
     if (small == 2) th = TileThresholds{64, 64, 8000};
     else if (small == 1) th = TileThresholds{256, 256, 2000};
+    else if (small == 3) th = TileThresholds{std::min(384, th.min_windows), std::min(384, th.accept_windows), th.max_dwords_per_window};
     int rc = build_plan(e, *c, W, H, p, pl.get(), split, th);
     if (rc) {
         pl->release_device();
@@ -2225,7 +2266,7 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
             bal->cur = bal->best;
             bal->phase = 3;
         } else if (!(p->flags & VJ_FLAG_COUNTERS) && (uint64_t)n_frames <= max_frames) {
-            balance_report(bal, out->timing.cascade_ms);
+            balance_report(bal, out->timing.cascade_ms, !e->tile_thresholds_set);
         }
     }
     out->timing.tile_split = pl->tile_split;
@@ -2541,7 +2582,7 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
             bal->cur = bal->best;
             bal->phase = 3;
         } else if (!(p_first->flags & VJ_FLAG_COUNTERS) && (uint64_t)n_frames <= max_frames) {
-            balance_report(bal, out_first->timing.cascade_ms);
+            balance_report(bal, out_first->timing.cascade_ms, !e->tile_thresholds_set);
         }
     }
     out_first->timing.tile_split = pl1->tile_split;
@@ -2642,8 +2683,9 @@ int vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int 
     } guard{nullptr};
     // (a chain balance already found for this workload by vj_detect's feedback is taken over; a stream does not search itself)
     const vj_env::Balance* bal = balance_of(e, c, width, height, *p, max_batch, false);
-    int rc = build_plan(e, *c, width, height, *p, s->plan.get(), bal ? bal->best : e->split_for(max_batch, *p),
-                        TileThresholds{e->tile_min_windows, e->tile_accept_windows, e->tile_max_dwords_per_window});
+    TileThresholds sth{e->tile_min_windows, e->tile_accept_windows, e->tile_max_dwords_per_window};
+    if (bal && bal->phase == 3 && bal->thr == 1 && !e->tile_thresholds_set) sth = TileThresholds{std::min(384, sth.min_windows), std::min(384, sth.accept_windows), sth.max_dwords_per_window};
+    int rc = build_plan(e, *c, width, height, *p, s->plan.get(), bal ? bal->best : e->split_for(max_batch, *p), sth);
     if (rc) {
         s->plan->release_device();
         return rc;

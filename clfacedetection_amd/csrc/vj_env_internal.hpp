@@ -213,8 +213,10 @@ struct vj_env {
     // calls and then frozen; vj_env_configure("tile_split", ...) or ("auto_balance", "0") keep the static values.
     struct Balance {
         float cur = 0, best = 0, best_ms = 0, cand_ms = 0;
-        int phase = 0;        // 0: measuring the start value, 1: climbing up, 2: climbing down, 3: frozen
+        int phase = 0;        // 0: measuring the start value, 1: climbing up, 2: climbing down, 3: frozen, 4: measuring the other tile thresholds, 5: probing a whole scale further
         int samples = 0, moved = 0, calls = 0;
+        int thr = 0;          // 0: the environment's tile thresholds; 1: scales whose tiles hold >= 384 windows go to tiles too
+        bool thr_tried = false, far_tried = false;
     };
     typedef std::tuple<PlanKey, int> BalanceKey;    // the plan key with split = 0, frames per call
     std::map<BalanceKey, Balance> balance;

@@ -545,6 +545,18 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
         assert np.array_equal(r1.rects, c1.rects) and np.array_equal(r2.rects, c2.rects)
         seen.append(r1.tile_split)
     assert len(set(seen[-6:])) == 1 and len(set(seen)) >= 2, seen
+    # one 16-megapixel frame per call is a workload of its own: the split search runs, then ONE more candidate — the lower
+    # tile thresholds (more scales on the tile chain) — and the search ends; same rectangles in every call
+    tree, _ = cascades("frontalface_alt_tree")
+    big = synth.batch(1, 4096, 4096, seed0=4001, kinds=("blocks",))
+    want = env.detect(tree, big)
+    seen = []
+    for _ in range(36):
+        r = env.detect(tree, big)
+        assert np.array_equal(r.rects, want.rects)
+        seen.append((r.tile_split, len(r.launches)))
+    assert len(set(seen[-8:])) == 1 and len(set(s for s, _ in seen)) >= 2, seen
+    del big
     # a share of the scales (a mask) starts without a move: the default is a fraction of the last tile scale of a WHOLE pyramid
     assert env.detect(c, frames, default_params(scales=[0, 1, 20, 21])).tile_split == 0.0
     env.configure("auto_balance", "reset")

@@ -12,7 +12,8 @@ def timed(c, df, n=6):
         ms.append(r.cascade_ms)
     return float(np.median(ms)), r
 for casc, B, H, W in (("frontalface_alt", 64, 1080, 1920), ("frontalface_default", 64, 1080, 1920), ("frontalface_default", 64, 480, 640),
-                      ("frontalface_alt2", 256, 720, 1280), ("eye", 64, 720, 1280), ("frontalface_alt", 16, 1080, 1920)):
+                      ("frontalface_alt2", 256, 720, 1280), ("eye", 64, 720, 1280), ("frontalface_alt", 16, 1080, 1920),
+                      ("frontalface_alt_tree", 1, 4096, 4096), ("frontalface_alt", 1, 4096, 4096)):
     c = Cascade.load(casc)
     t = torch.from_numpy(synth.batch(B, H, W, seed0=1)).cuda(); torch.cuda.synchronize()
     df = DeviceFrames.from_torch(t)
@@ -21,13 +22,13 @@ for casc, B, H, W in (("frontalface_alt", 64, 1080, 1920), ("frontalface_default
     static_ms, rs = timed(c, df)
     env.configure("auto_balance", "1")
     calls = 0
-    while True:                       # the first calls of a new workload: three per candidate split
+    last = []
+    while True:                       # the first calls of a new workload: three per candidate; over when nine calls in a row agree
         r = env.detect(c, df); calls += 1
-        if calls >= 3 and calls % 3 == 0:
-            a = [env.detect(c, df).tile_split for _ in range(3)]; calls += 3
-            if len(set(a)) == 1 and calls >= 12 or calls > 60: break
+        last = (last + [(r.tile_split, len(r.launches), tuple(l["lds_class"] for l in r.launches))])[-9:]
+        if (len(last) == 9 and len(set(last)) == 1) or calls > 120: break
     bal_ms, rb = timed(c, df)
     same = bool(np.array_equal(rs.rects, rb.rects))
     print(f"{casc} {B}x{W}x{H}: static split {rs.tile_split:.2f} {static_ms:.2f} ms | balanced split {rb.tile_split:.2f} {bal_ms:.2f} ms "
-          f"({100 * (static_ms / bal_ms - 1):+.1f} %) after {calls} calls, same rectangles: {same}", flush=True)
+          f"({100 * (static_ms / bal_ms - 1):+.1f} %, {len(rb.launches)} launches against {len(rs.launches)}) after {calls} calls, same rectangles: {same}", flush=True)
     del t

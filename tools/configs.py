@@ -34,7 +34,7 @@ elif what == "cv":
     run = lambda i: env.detect_opencv(c, df)
 else:
     sys.exit(__doc__)
-for i in range(3):
+for i in range(30 if what in ("config4", "config5", "config5raw") else 3):      # (the first calls of these workloads settle the chain balance)
     run(i)
 torch.cuda.synchronize()
 wall, last = [], None
