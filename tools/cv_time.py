@@ -8,7 +8,8 @@ args = [a for a in sys.argv[1:] if "=" not in a]
 names = args[0].split(",") if args else ["frontalface_alt"]
 B = int(args[1]) if len(args) > 1 else 64
 env = Environment(0)
-t = torch.from_numpy(synth.batch(B, 1080, 1920, seed0=1)).cuda(); torch.cuda.synchronize()
+H, W = int(os.environ.get("H", "1080")), int(os.environ.get("W", "1920"))      # frame size: H=720 W=1280 python tools/cv_time.py ...
+t = torch.from_numpy(synth.batch(B, H, W, seed0=1)).cuda(); torch.cuda.synchronize()
 df = DeviceFrames.from_torch(t)
 for kv in sys.argv[1:]:
     if "=" in kv:
