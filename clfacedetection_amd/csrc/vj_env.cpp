@@ -1773,7 +1773,8 @@ void vj_env_destroy(vj_env* e) {
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     drop_plans(e);
     for (DevBuf* b : {&e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_tilted, &e->d_out,
-                      &e->d_skip_bits, &e->d_rois, &e->d_roi_units, &e->d_roi_det, &e->d_group, &e->d_cv_det, &e->d_cv_counts})
+                      &e->d_skip_bits, &e->d_rois, &e->d_roi_units, &e->d_roi_det, &e->d_roi_tiles, &e->d_group, &e->d_cv_det, &e->d_cv_counts,
+                      &e->d_cv_accept, &e->d_cv_tq})
         b->release();
     e->lane0.destroy();
     for (DevBuf& b : e->d_q) b.release();
