@@ -504,7 +504,7 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
     env.configure("auto_balance", "1")
     first = env.detect(c, frames)
     splits = []
-    for _ in range(48):
+    for _ in range(100):
         r = env.detect(c, frames)
         assert np.array_equal(r.rects, first.rects)
         splits.append(r.tile_split)
@@ -528,7 +528,7 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
         ref = env.detect(alt, frames, p)
         assert ref.tile_split == 1.0 and not any(l["kind"] == "tile" for l in ref.launches)
         seen = []
-        for _ in range(40):
+        for _ in range(100):
             r = env.detect(alt, frames, p)
             assert np.array_equal(r.rects, ref.rects)
             seen.append(r.tile_split)
@@ -540,7 +540,7 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
     eye, _ = cascades("eye")
     c1, c2 = env.detect_chain(c, eye, frames)
     seen = []
-    for _ in range(30):
+    for _ in range(100):
         r1, r2 = env.detect_chain(c, eye, frames)
         assert np.array_equal(r1.rects, c1.rects) and np.array_equal(r2.rects, c2.rects)
         seen.append(r1.tile_split)
@@ -551,7 +551,7 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
     big = synth.batch(1, 4096, 4096, seed0=4001, kinds=("blocks",))
     want = env.detect(tree, big)
     seen = []
-    for _ in range(36):
+    for _ in range(80):
         r = env.detect(tree, big)
         assert np.array_equal(r.rects, want.rects)
         seen.append((r.tile_split, len(r.launches)))
