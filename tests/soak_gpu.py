@@ -2,7 +2,7 @@
 `python tests/soak_gpu.py [seconds] [first seed] [max width] [max height]`; not collected by pytest).  Every case draws a cascade, a frame kind
 and size, size limits, a scale factor, a mode (exhaustive grid, the four CPU variants' skip sets incl. the block variant's f64
 grids, the OpenCV profile on tiles and rows, the two-cascade chain with or without grouping, host-supplied regions incl. stage
-trees), a batch size and a few tunables; rectangles and per-stage counts must equal
+trees, a batch workload repeated while the chain-balance search runs), a batch size and a few tunables; rectangles and per-stage counts must equal
 the oracle's.  Prints one line per failure and a summary; exit code 1 if anything differed."""
 import os
 import sys
@@ -54,7 +54,7 @@ seed = seed0
 while time.time() < t_end:
     rng = np.random.default_rng(770000 + seed)
     mode = ["grid", "grid", "grid", "skip_list", "skip_row", "block_row", "block_list", "opencv", "opencv", "chain", "chain_grouped", "rois",
-            "rois"][int(rng.integers(0, 13))]
+            "rois", "feedback"][int(rng.integers(0, 14))]
     name = NAMES[int(rng.integers(0, len(NAMES)))]
     c, a = CASC[name]
     linear = bool(np.all(a.stage_next == -1))
@@ -79,7 +79,21 @@ while time.time() < t_end:
     desc = (seed, mode, name, kind, h, w, nb, tun)
     ok = True
     try:
-        if mode in ("grid", "skip_list", "skip_row", "block_row", "block_list"):
+        if mode == "feedback":                    # a batch workload repeated: the chain-balance search moves between plans, never the result
+            nb = int(rng.integers(8, 12))
+            imgs = np.stack([make_frame(kind, 9000 + seed + k, min(h, 420), min(w, 520)) for k in range(nb)])
+            p = default_params(scale_factor=[1.1, 1.2][int(rng.integers(0, 2))])
+            first = env.detect(c, imgs, p)
+            splits = set()
+            for _ in range(int(rng.integers(12, 40))):
+                r = env.detect(c, imgs, p)
+                ok &= np.array_equal(r.rects, first.rects)
+                splits.add(r.tile_split)
+            f = int(rng.integers(0, nb))
+            ro, _ = o.detect(a, imgs[f], scale_factor=[1.1, 1.2][0 if p.scale_factor < 1.15 else 1])
+            ok &= rows(first.rects[first.rects["frame"] == f]) == rows(ro)
+            desc += (nb, sorted(splits))
+        elif mode in ("grid", "skip_list", "skip_row", "block_row", "block_list"):
             mn = (0, 0) if rng.random() < 0.6 else (int(rng.integers(20, 70)),) * 2
             mx = (0, 0) if rng.random() < 0.7 else (int(rng.integers(80, 300)),) * 2
             sf = [1.1, 1.2, 1.05, 1.3, 1.5][int(rng.integers(0, 5))]
@@ -155,6 +169,8 @@ while time.time() < t_end:
         desc += (repr(e),)
     for k in tun:
         env.configure(k, DEFAULTS[k])
+        if k == "tile_split":
+            env.configure("auto_balance", "reset")     # (a hand-set split switches the feedback off until it is reset)
     n_cases += 1
     by_mode[mode] = by_mode.get(mode, 0) + 1
     if not ok:
