@@ -116,7 +116,10 @@ struct SpBlock {
 
 constexpr int UNIT_WINDOWS = 512;   // windows per wave-unit == per-wave LDS queue capacity
 constexpr int WAVES_PER_BLOCK = 3;    // waves per workgroup of the global-gather kernels: with one workgroup per CU next to the tile
-                                      // chain, 2 starve the gather chain (+12 ms), 4 slow the tiles (+1.5 ms); measured
+                                      // chain, 2 starve the gather chain (+12 ms); batches run 4 (GATHER_WAVES_MAX: the gather chain is
+                                      // 11 % faster, the tiles 1 % slower, and the balance moves three quarters of a scale further:
+                                      // profiles/r03_notes.md #6g), single frames and stage trees 3 (CascadeArgs::gather_waves)
+constexpr int GATHER_WAVES_MAX = 4;   // (the workgroup's queues: 4 KiB of LDS per wave, 16 KiB = what the tile classes leave free)
 constexpr int MAX_SCALES = 128;
 constexpr int MAX_PASSES = 8;         // == VJ_MAX_PASSES
 constexpr uint32_t Q_PARTS = 8;       // parts of a scale's survivor-queue segment, by frame group (one per XCD to drain)
@@ -150,7 +153,8 @@ struct CascadeArgs {
     uint32_t sum_bytes;         // n_frames * frame_elems * 4 (< 2^32)
     uint32_t stride;            // elements per image row (W + 1)
     uint32_t stage_begin, stage_end;  // stages [begin, end) evaluated by this pass
-    uint32_t total_waves;       // gridDim.x * WAVES_PER_BLOCK
+    uint32_t total_waves;       // gridDim.x * gather_waves
+    uint32_t gather_waves;      // waves per workgroup of cascade_pass / cascade_roi_pass (3 or 4; stage trees: 3)
     uint32_t xcd_affinity;      // grid pass: waves of one XCD share a contiguous part of the (frame, unit) list
     const QEntry*   q_in;       // survivor queue read by this pass (passes > 0)
     const uint32_t* q_in_count; // entry counts of q_in, [scale][Q_PARTS]

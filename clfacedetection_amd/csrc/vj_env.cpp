@@ -1025,7 +1025,10 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
         ca.frame_elems = pl->frame_elems;
         ca.sum_bytes = (uint32_t)((uint64_t)pl->frame_elems * 4u * (uint64_t)nf);
         ca.stride = (uint32_t)W + 1u;
-        ca.total_waves = (uint32_t)n_blocks * WAVES_PER_BLOCK;
+        // waves per workgroup of the gather chain: four for batches, three for single frames and for stage trees (their
+        // workgroups carry a second LDS array); the launchers clamp, the kernels read blockDim
+        ca.gather_waves = (uint32_t)e->gather_waves_for(nf, pl->general);
+        ca.total_waves = (uint32_t)n_blocks * ca.gather_waves;
         ca.det = (DetEntry*)L->d_det.p;
         ca.det_count = d_det_count;
         ca.det_cap = L->det_cap;
@@ -1210,7 +1213,7 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
                 if ((rc = end_launch(sB))) return rc;
             } else if (!hrc && ca.n_units > 0) {
                 CascadeArgs ga = queue_args(0);
-                ga.total_waves = (uint32_t)b_blocks * WAVES_PER_BLOCK;
+                ga.total_waves = (uint32_t)b_blocks * ga.gather_waves;
                 if ((rc = begin_launch(VJ_LAUNCH_GRID, 0, ga.stage_begin, ga.stage_end, 0, sB))) return rc;
                 ga.stage_entered = launch_counters();
                 hrc = launch_cascade_pass(ga, true, pl->trees, n_pass == 1, count, general_kernel && n_pass == 1, b_blocks, sB);
@@ -1219,7 +1222,7 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
                     CascadeArgs qa = queue_args(ps);
                     // (next to the tiles one workgroup per CU; a stage tree's chains are latency-bound: all of them)
                     const int qb = split_sets ? n_blocks : b_blocks;
-                    qa.total_waves = (uint32_t)qb * WAVES_PER_BLOCK;
+                    qa.total_waves = (uint32_t)qb * qa.gather_waves;
                     if ((rc = begin_launch(VJ_LAUNCH_QUEUE, 0, qa.stage_begin, qa.stage_end, 0, sB))) return rc;
                     qa.stage_entered = launch_counters();
                     hrc = launch_cascade_pass(qa, false, pl->trees, pass_is_last(ps), count, false, qb, sB);
@@ -1521,6 +1524,7 @@ static void fill_region_args(vj_env* e, Lane* L, Plan* pl2, const vj_cascade* se
     ca.frame_elems = pl2->frame_elems;
     ca.sum_bytes = (uint32_t)((uint64_t)pl2->frame_elems * 4u * (uint64_t)nf);
     ca.stride = stride;
+    ca.gather_waves = (uint32_t)e->gather_waves_for(nf, pl2->general);
     ca.stage_begin = 0;
     ca.stage_end = pl2->general ? pl2->pass_bounds.back() : (uint32_t)pl2->stages.size();   // stage trees: positions in the sweep order
     ca.identity_order = pl2->general ? 0u : 1u;
@@ -1992,6 +1996,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         HIP_TRY(hipStreamSynchronize(e->stream));
         e->det_cap_init = (uint32_t)v;
         e->lane0.det_cap = 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "gather_waves") == 0) {   // waves per workgroup of the global-gather kernels: 3, 4, or -1 = 4 for calls of >= 8 frames
+        e->gather_waves = atoi(value);
         return VJ_OK;
     }
     if (strcmp(key, "concurrent_blocks_per_cu") == 0) {

@@ -166,15 +166,23 @@ struct vj_env {
     int max_subbatch = 0;      // > 0: cap on frames per sub-batch (tests)
     uint32_t det_cap_init = 1u << 16;  // initial capacity of the detection buffer (grows on overflow)
     int concurrent = 1;   // 1: the tile chain and the global-gather chain overlap on two streams
+    int gather_waves = -1;              // waves per workgroup of the global-gather kernels (-1: 4 for calls of >= 8 frames, else 3)
+    int gather_waves_for(int n_frames, bool general) const {
+        if (general) return vj::WAVES_PER_BLOCK;
+        const int w = gather_waves > 0 ? gather_waves : (n_frames >= 8 ? vj::GATHER_WAVES_MAX : vj::WAVES_PER_BLOCK);
+        return std::min(std::max(w, 1), (int)vj::GATHER_WAVES_MAX);
+    }
     int concurrent_blocks_per_cu = 1;   // workgroups per CU of the global-gather chain while it overlaps
     // scales' worth of tile work handed to the global-gather chain (largest tile scales first), by batch size: a single
     // frame is bound by the latency of the gather chain's thin queue pass (measured, 1080p / frontalface_alt: 1 frame
     // 1.20 / 1.46 / 1.46 ms at split 0 / 0.5 / 1.25; 4 frames 3.50 / 3.61 / 3.96; 16 frames 12.51 / 12.25 / 12.36;
     // 64 frames — / 48.0 / 54.0), so small batches keep everything they can on the tiles
-    float tile_split = 0.75f;           // batches of >= 32 frames (64 x 1080p: 47.68 / 47.27 / 46.90 / 46.68 / 47.55 ms for 0.25 / 0.5 / 0.625 / 0.75 / 1; 32: 23.95 / 23.70 / 23.39 / 23.86)
-    float tile_split_mid = 0.5f;        // 5 .. 31 frames (8 x 1080p: 6.14 / 6.06 / 6.03 / 6.10 / 6.33 ms for 0 / 0.25 / 0.5 / 0.75 / 1)
+    float tile_split = 1.5f;            // batches of >= 32 frames (four gather waves; 64 x 1080p: 46.70 / 46.24 / 45.57 / 45.16 / 45.55 / 46.72 ms for 0.75 / 1 / 1.25 / 1.5 / 1.75 / 2; 32: 23.39 / 23.16 / 22.80 / 22.62 / 22.78 / 23.38)
+    float tile_split_mid = 1.25f;       // 8 .. 31 frames (16 x 1080p: 11.81 / 11.67 / 11.47 / 11.52 / 11.86 for 0.75 ... 1.75; 8: 6.03 / 5.95 / 5.97 / 6.24); 5 .. 7 frames (three gather waves): at most 0.5
     float tile_split_small = 0.0f;      // <= 4 frames
-    float split_for(int n_frames) const { return n_frames <= 4 ? tile_split_small : n_frames < 32 ? tile_split_mid : tile_split; }
+    float split_for(int n_frames) const {
+        return n_frames <= 4 ? tile_split_small : n_frames < 8 ? std::min(tile_split_mid, 0.5f) : n_frames < 32 ? tile_split_mid : tile_split;
+    }
     // (the defaults are fractions of the last tile scale of a WHOLE pyramid; a share of the scales (vj_shard_scales) may end with a
     // scale of half a million windows: it starts without a move and lets the feedback find one)
     float split_for(int n_frames, const vj_params& p) const {

@@ -13,6 +13,7 @@
 // the reference's order.  This file MUST be compiled with -ffp-contract=off; HIP's
 // default correctly-rounded f32 divide/sqrt is relied upon.
 #include <hip/hip_runtime.h>
+#include <algorithm>
 #include <type_traits>
 #include "vj_device.hpp"
 #include "vj_devutil.hpp"
@@ -939,13 +940,15 @@ __device__ __forceinline__ void run_stages_general(const CascadeArgs& a, rsrc_t 
 }
 
 template <bool FROM_GRID, bool TREES, bool LAST, bool COUNT, bool GENERAL, int NW = 1>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs a) {
-    __shared__ QEntry lds_q[WAVES_PER_BLOCK * UNIT_WINDOWS];
+__global__ __launch_bounds__(GATHER_WAVES_MAX * 64) void cascade_pass(CascadeArgs a) {
+    // (stage trees are launched with WAVES_PER_BLOCK waves: their second array would not fit next to the tiles otherwise)
+    __shared__ QEntry lds_q[(GENERAL ? WAVES_PER_BLOCK : GATHER_WAVES_MAX) * UNIT_WINDOWS];
     __shared__ int32_t lds_tgt[GENERAL ? WAVES_PER_BLOCK * UNIT_WINDOWS : 1];
     const uint32_t lane = lane_id();
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const uint32_t wpb = blockDim.x >> 6;     // the host's choice (CascadeArgs::gather_waves, clamped by the launcher)
     QEntry* q = lds_q + wib * UNIT_WINDOWS;
-    const uint32_t rank = blockIdx.x * WAVES_PER_BLOCK + wib;
+    const uint32_t rank = blockIdx.x * wpb + wib;
     kptr<ScaleDev> scales = as_k(a.scales);
     // the whole batch of sum images behind one descriptor (host keeps it below 4 GiB)
     const rsrc_t img = make_rsrc(a.sum, a.sum_bytes);
@@ -962,8 +965,8 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
             const uint32_t xcd = blockIdx.x & 7u;
             u_begin = (uint32_t)((unsigned long long)total_units * xcd / 8u);
             u_end = (uint32_t)((unsigned long long)total_units * (xcd + 1u) / 8u);
-            u_step = ((gridDim.x - xcd + 7u) >> 3) * WAVES_PER_BLOCK;
-            u_first = u_begin + (blockIdx.x >> 3) * WAVES_PER_BLOCK + wib;
+            u_step = ((gridDim.x - xcd + 7u) >> 3) * wpb;
+            u_first = u_begin + (blockIdx.x >> 3) * wpb + wib;
         }
         for (uint32_t u = u_first; u < u_end; u += u_step) {
             const uint32_t frame = u / a.n_units;
@@ -1065,7 +1068,7 @@ __global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_pass(CascadeArgs
 #pragma unroll
             for (uint32_t k = 0; k < N_CNT; ++k) n_chunks += (my_cnt[k] + chunk - 1u) / chunk;
             n_chunks = wave_total(n_chunks);
-            if (blockIdx.x >= max((n_chunks + WAVES_PER_BLOCK - 1u) / WAVES_PER_BLOCK, 1u)) return;
+            if (blockIdx.x >= max((n_chunks + wpb - 1u) / wpb, 1u)) return;
         }
         // chunks per part (counter i belongs to part i % Q_PARTS, and 64 % Q_PARTS == 0: lane l sums part l % Q_PARTS):
         // an empty or used-up part is left without walking its scales
@@ -1307,8 +1310,8 @@ __global__ __launch_bounds__(256) void roi_plan_units(RoiArgs r, CascadeArgs a) 
 }
 
 template <bool TREES, bool COUNT, bool GENERAL>
-__global__ __launch_bounds__(WAVES_PER_BLOCK * 64) void cascade_roi_pass(RoiArgs r, CascadeArgs a) {
-    __shared__ QEntry lds_q[WAVES_PER_BLOCK * UNIT_WINDOWS];
+__global__ __launch_bounds__(GATHER_WAVES_MAX * 64) void cascade_roi_pass(RoiArgs r, CascadeArgs a) {
+    __shared__ QEntry lds_q[(GENERAL ? WAVES_PER_BLOCK : GATHER_WAVES_MAX) * UNIT_WINDOWS];
     __shared__ int32_t lds_tgt[GENERAL ? WAVES_PER_BLOCK * UNIT_WINDOWS : 1];   // stage trees: the stage every queued window visits next
     const uint32_t lane = lane_id();
     const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -1396,12 +1399,19 @@ static void launch_roi_pass(const RoiArgs& r, const CascadeArgs& a, bool trees, 
     }
 }
 
+// Threads per workgroup of the global-gather kernels: the host's choice (CascadeArgs::gather_waves), within what the kernels' LDS
+// arrays hold; the kernels read the same field.
+static uint32_t gather_block_threads(const CascadeArgs& a, bool general) {
+    const uint32_t most = general ? (uint32_t)WAVES_PER_BLOCK : (uint32_t)GATHER_WAVES_MAX;
+    return 64u * std::min(std::max(a.gather_waves, 1u), most);
+}
+
 int launch_roi_chain(const RoiArgs& r, const CascadeArgs& a, bool from_dets, bool trees, bool count, bool general, int n_blocks,
                      void* stream_, void* stream2_, void* fork_ev_, void* join_ev_) {
     hipStream_t stream = (hipStream_t)stream_, stream2 = (hipStream_t)stream2_;
     if (from_dets) hipLaunchKernelGGL(dets_to_rois, dim3(256), dim3(256), 0, stream, r);
     hipLaunchKernelGGL(roi_plan_units, dim3(512), dim3(256), 0, stream, r, a);
-    dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
+    dim3 g(n_blocks), b(gather_block_threads(a, general));
     // the regions' tiles (LDS / VALU-bound) and the thin units of the region pass (texture-address-bound) side by side on two
     // streams when the caller lends a second one: the gather pass first, the tile workgroups fill the CUs next to it
     const bool two = r.tiles != nullptr && stream2 != nullptr;
@@ -2300,7 +2310,7 @@ int launch_cascade_tile_pass(const CascadeArgs& a, bool trees, bool count, bool 
 
 template <bool FROM_GRID, bool TREES>
 static void launch_variant(const CascadeArgs& a, bool last, bool count, int n_blocks, hipStream_t stream) {
-    dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
+    dim3 g(n_blocks), b(gather_block_threads(a, false));
     if constexpr (!FROM_GRID && !TREES) {
         if (a.wide_tail != 0u) {   // queue passes of a small batch: TAIL_NW windows per step of the stump-parallel tail
             if (last) {
@@ -2324,7 +2334,7 @@ static void launch_variant(const CascadeArgs& a, bool last, bool count, int n_bl
 
 template <bool FROM_GRID, bool TREES>
 static void launch_general(const CascadeArgs& a, bool count, int n_blocks, hipStream_t stream) {
-    dim3 g(n_blocks), b(WAVES_PER_BLOCK * 64);
+    dim3 g(n_blocks), b(gather_block_threads(a, true));
     if (count) hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, true, true>), g, b, 0, stream, a);
     else       hipLaunchKernelGGL((cascade_pass<FROM_GRID, TREES, true, false, true>), g, b, 0, stream, a);
 }

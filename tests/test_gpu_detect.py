@@ -144,7 +144,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("concurrent", 1)
         env.configure("tile_lds_reserve_kb", 16)
         env.configure("global_blocks", 0)
-        env.configure("tile_split", "0,0.5,0.75")
+        env.configure("tile_split", "0,1.25,1.5")
         env.configure("grid_block_w", 32)
         # LDS-tile path off / small / large tiles / shallow / deep: the tile and the
         # global-gather paths agree bit for bit
@@ -168,7 +168,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("concurrent", 1)
         env.configure("tile_lds_reserve_kb", 16)
         env.configure("global_blocks", 0)
-        env.configure("tile_split", "0,0.5,0.75")
+        env.configure("tile_split", "0,1.25,1.5")
         env.configure("grid_block_w", 32)
         env.configure("pass_split", "")
         env.configure("blocks_per_cu", 8)
@@ -511,9 +511,9 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
     assert len(set(splits[-6:])) == 1 and all(0.0 <= s <= 3.0 for s in splits)
     ro, _ = oracle.detect(a, frames[5])
     assert as_list(first.rects[first.rects["frame"] == 5]) == as_list(ro)
-    env.configure("tile_split", "0,0.5,0.75")             # static values: the feedback is off
+    env.configure("tile_split", "0,1.25,1.5")             # static values: the feedback is off
     try:
-        assert {env.detect(c, frames).tile_split for _ in range(7)} == {0.5}
+        assert {env.detect(c, frames).tile_split for _ in range(7)} == {1.25}      # (12 frames: the value for 8 .. 31)
         assert np.array_equal(env.detect(c, frames).rects, first.rects)
     finally:
         env.configure("auto_balance", "reset")
@@ -534,7 +534,7 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
             seen.append(r.tile_split)
         assert len(set(seen[-6:])) == 1 and len(set(seen)) >= 3, seen
     finally:
-        env.configure("tile_split", "0,0.5,0.75")
+        env.configure("tile_split", "0,1.25,1.5")
         env.configure("auto_balance", "reset")
     # vj_detect_chain searches the balance of its first cascade the same way: same two results in every call of the search
     eye, _ = cascades("eye")
