@@ -8,9 +8,11 @@ N > 1 — the all-gather of detection rectangles) over one batch of synthetic fr
 is already resident in HBM.  BASELINE config 3 is a FIXED batch of 64 frames sharded over the GPUs, so the headline
 line is strong scaling: --frames is the whole job's batch and rank r takes its vj_shard_frames block of whole
 frames (it integrates only its own frames; the only collective is the final gather of rectangles).  For N > 1 the
-same run also times the weak-scaling variant (--frames per GPU) into `weak_scaling`; `per_rank_ms_per_step` and
-`rccl_ranks` say what every rank did and how many ranks the collective really spanned.  `--scaling weak` makes
-the weak variant the headline instead.  At N = 1 the two are the same run.
+same run also times the weak-scaling variant (--frames per GPU) into `weak_scaling` and the same fixed job under the OTHER
+split into `other_sharding` (--shard levels: BASELINE config 3 as worded — the pyramid levels sharded, every rank
+integrating every frame; --shard frames, the default and the better split, shards whole frames); `per_rank_ms_per_step`,
+`allgather_ms_per_step` and `collectives_per_step` say what every rank did and what the one collective cost.
+`--scaling weak` makes the weak variant the headline instead.  At N = 1 all of them are the same run.
 
     python bench.py --gpus 1 --steps 20 --warmup 3
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
@@ -53,7 +55,6 @@ sys.path.insert(0, ROOT)
 # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec; L2 ~34.5 TB/s aggregate; LDS ~75 TB/s aggregate for ds_read_b32 gathers
 # (128 B/clk/CU x 256 CUs at ~2.4 GHz; b64 / b128 reads reach ~150 TB/s but a dword gather cannot use them)
 PEAK_GBPS = {"hbm": 8000.0, "l2": 34500.0, "lds": 75000.0}
-TA_GBPS = 256 * 64 * 4 / 49 * 2.1     # 2809: measured gather ceiling of the texture-address path (see below)
 KERNEL_OF = {"tile": ("vj::cascade_tile_pass<false, false, true>", "lds"),
              "block": ("vj::cascade_tile_pass<false, false, false>", "l2"),
              "grid": ("vj::cascade_pass<true, false, *, false, false>", "l2"),
@@ -79,6 +80,10 @@ def main() -> int:
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=64,
                     help="1080p frames per step: of the whole job (strong scaling) or per GPU (weak)")
+    ap.add_argument("--shard", choices=("frames", "levels"), default="frames",
+                    help="what the headline shards for N > 1: whole frames (vj_shard_frames; the better split for a batch) or the "
+                         "pyramid levels (vj_shard_scales: BASELINE config 3 as worded — every rank integrates every frame and runs "
+                         "its share of the scales); the other split of the same fixed job is timed in the same run (`other_sharding`)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
                     help="strong: --frames frames in total, sharded by whole frames (BASELINE config 3 as stated); "
                          "weak: --frames frames per GPU")
@@ -141,9 +146,15 @@ def main() -> int:
             dist.barrier()
         torch.cuda.synchronize()
 
-    def measure(scaling):
-        """One scaling variant: this rank's frames on the device, a counted run, warm-up, args.steps timed steps."""
-        if scaling == "strong":
+    gather = multigpu.RectGather(device=coll_dev) if world > 1 else None      # one collective per step, capacity kept across steps
+
+    def measure(scaling, shard="frames"):
+        """One variant: this rank's frames on the device, a counted run, warm-up, args.steps timed steps."""
+        p = default_params()
+        if shard == "levels":      # every rank: all frames of the job, its share of the pyramid levels (strong scaling only)
+            first, B, job_frames = 0, args.frames, args.frames
+            p = default_params(scales=casc.shard_scales(W, H, rank, world)) if world > 1 else p
+        elif scaling == "strong":
             mine = multigpu.shard_frames(args.frames, rank, world)      # == vj_shard_frames: contiguous blocks of whole frames
             first, B, job_frames = mine.start, len(mine), args.frames
         else:
@@ -161,14 +172,16 @@ def main() -> int:
             if world > 1:
                 rects = rects.copy()
                 rects["frame"] += first             # global frame index
-                rects = multigpu.allgather_rects(rects, device=coll_dev)
+                rects = gather(rects)
             return r, rects
 
         def step(params):
             return finish(env.detect(casc, dframes if B > 0 else [], params))
 
         # one counted run: algorithmic bytes per launch (the counted kernel variants are slower and never timed)
-        counted, _ = step(default_params(flags=VJ_FLAG_COUNTERS))
+        pc = default_params(flags=VJ_FLAG_COUNTERS)
+        pc.scale_mask[0], pc.scale_mask[1] = p.scale_mask[0], p.scale_mask[1]
+        counted, _ = step(pc)
         # The timed steps go through a vj_stream (two batches in flight): step k's read-back, decode and sort on the host
         # overlap step k+1's kernels.  Every step still does everything — integral images, all cascade passes, read-back,
         # sorted rectangles (and the all-gather for N > 1) — and all of it completes inside the timed bracket; the frames
@@ -192,6 +205,8 @@ def main() -> int:
         for _ in run_steps(args.warmup):
             pass
         barrier()
+        if gather is not None:
+            gather.total_ms, g0 = 0.0, gather.n_collectives
         t0 = time.perf_counter()
         m = {"integral_ms": 0.0, "cascade_ms": 0.0, "pass_ms": None, "launch_ms": None, "launches": None,
              "n_det_total": 0, "timed_rects": None}
@@ -220,17 +235,26 @@ def main() -> int:
         if stream is not None:
             stream.close()
         K = max(args.steps, 1)
+        m.update(shard=shard, allgather_ms=(round(gather.total_ms / K, 4) if gather is not None else None),
+                 collectives_per_step=(round((gather.n_collectives - g0) / K, 3) if gather is not None else None))
         m.update(scaling=scaling, first=first, B=B, job_frames=job_frames, frames_h=frames_h, dframes=dframes, counted=counted,
                  elapsed=elapsed, ms_per_step=1e3 * elapsed / K, per_rank_ms=[round(1e3 * x / K, 4) for x in per_rank],
                  value=windows_per_frame * job_frames * args.steps / elapsed, keep=frames_d)
         return m
 
-    m = measure(args.scaling)
-    other = None
-    if world > 1:      # the other variant in the same run, so that both figures come from the same box and build
-        o = measure("weak" if args.scaling == "strong" else "strong")
-        other = {"scaling": o["scaling"], "value": round(o["value"], 1), "unit": "windows/s", "ms_per_step": round(o["ms_per_step"], 4),
-                 "frames_per_step_whole_job": o["job_frames"], "per_rank_ms_per_step": o["per_rank_ms"]}
+    m = measure(args.scaling if args.shard == "frames" else "strong", args.shard)
+    other = other_shard = None
+    if world > 1:      # the other variants in the same run, so that every figure comes from the same box and build
+        brief = lambda o: {"scaling": o["scaling"], "shard": o["shard"], "value": round(o["value"], 1), "unit": "windows/s",
+                           "ms_per_step": round(o["ms_per_step"], 4), "frames_per_step_whole_job": o["job_frames"],
+                           "per_rank_ms_per_step": o["per_rank_ms"], "allgather_ms_per_step": o["allgather_ms"],
+                           "collectives_per_step": o["collectives_per_step"]}
+        if args.shard == "frames":
+            o = measure("weak" if args.scaling == "strong" else "strong")
+            other = brief(o)
+            del o
+        o = measure("strong", "levels" if args.shard == "frames" else "frames")      # the same fixed job under the other split
+        other_shard = brief(o)
         del o
     elapsed, ms_per_step, value = m["elapsed"], m["ms_per_step"], m["value"]
     B, frames_h, dframes, counted = m["B"], m["frames_h"], m["dframes"], m["counted"]
@@ -271,12 +295,17 @@ def main() -> int:
                                 "achieved": round(ach, 1), "peak": PEAK_GBPS[bound], "unit": "GB/s",
                                 "frac": round(ach / PEAK_GBPS[bound], 4)}
             if bound == "l2":
-                # what really binds a global gather is the texture-address unit's rate for uncoalesced lanes, which depends on
-                # the lanes' stride: tools/microbench/ta_gather.hip (profiles/r01_ta_gather_microbench.log) measured 49 cycles
-                # per wave-load at a stride of 20 bytes (neighbouring windows at s = 5) and 77 for lanes random inside the L1
-                per_kernel[kind]["texture_address_rate"] = {
-                    "peak": round(TA_GBPS, 1), "frac": round(ach / TA_GBPS, 4), "unit": "GB/s",
-                    "basis": "256 CUs x 64 lanes x 4 B / 49 cycles x 2.1 GHz: dword gathers at a lane stride of 20 B, measured"}
+                # what binds a global gather is the texture-address unit, one per CU, which takes every lane of an uncoalesced
+                # wave-load in turn: the figure that compares passes is CU-cycles per lane-gather (4 bytes each; profiles/r04_notes.md
+                # has the counters).  Round 3 printed a "ceiling" measured at ONE lane stride here, which a pass that spans strides
+                # 3.8 ... 50 can beat: removed.
+                w_in = sum(l["stage_entered"][0] for l in counted.launches if l["kind"] == kind) if kind != "queue" else 0
+                lane_gathers = (b - 48 * w_in) / 4 + 8 * w_in      # four corners per evaluated rectangle + the variance's 4 + 4 corners
+                per_kernel[kind]["texture_address"] = {
+                    "lane_gathers_per_step": int(lane_gathers),
+                    "cu_ns_per_lane_gather": round(grp["ms"] * 1e6 * 256 / max(lane_gathers, 1), 4),
+                    "note": "launch time x 256 CUs / lane-gathers (rectangle corners + the variance's eight corners); "
+                            "x clock in GHz = texture-address cycles per lane"}
         int_ach = 13 * W * H * B / (integral_ms / K * 1e-3) / 1e9
         per_kernel["integral"] = {"kernel": "vj::band_colsum + vj::band_scan + vj::band_rows", "bound": "hbm", "launches_per_step": 3,
                                   "ms_per_step": round(integral_ms / K, 4), "algorithmic_bytes_per_launch": 13 * W * H * B,
@@ -380,16 +409,19 @@ def main() -> int:
                                    f"{world} GPU{'s' if world > 1 else ''}), haarcascade_{args.cascade}, scaleFactor 1.1f, raw candidates, "
                                    f"frames resident in HBM",
                        "frames_per_step_whole_job": m["job_frames"], "frames_on_rank_0": B, "windows_per_frame": windows_per_frame,
-                       "parallelism": f"frames sharded over {world} rank{'s' if world > 1 else ''} (vj_shard_frames), "
-                                      "no data-path collective, one all-gather of rectangles" if world > 1 else "single GPU",
+                       "parallelism": ((f"whole frames sharded over {world} ranks (vj_shard_frames)" if m["shard"] == "frames" else
+                                        f"pyramid levels sharded over {world} ranks (vj_shard_scales; every rank integrates every frame)") +
+                                       ", no data-path collective, ONE all-gather of fixed-capacity rectangle blocks per step") if world > 1 else "single GPU",
                        "pass_split": [x[0] for x in counted.passes], "device": env.device_name,
                        "pipeline": "blocking vj_detect calls" if args.no_pipeline else "vj_stream, two batches in flight"},
             "mpix_per_s": round(W * H * m["job_frames"] * args.steps / elapsed / 1e6, 1),
             "frames_per_s": round(m["job_frames"] * args.steps / elapsed, 1),
             "per_rank_ms_per_step": m["per_rank_ms"],
-            "rccl_ranks": (dist.get_world_size() if args.backend == "nccl" else 0) if world > 1 else 1,
+            "torch_world_size": (dist.get_world_size() if world > 1 else 1),      # (torch's number; the C++ host reads ncclCommCount: include/vj_rccl.h)
             "collective_backend": (args.backend if world > 1 else None),
+            "allgather_ms_per_step": m["allgather_ms"], "collectives_per_step": m["collectives_per_step"],
             ("weak_scaling" if m["scaling"] == "strong" else "strong_scaling"): other,
+            "other_sharding": other_shard,
             "detections_last_step": int(n_det_total),
             "kernel_ms_per_step": {"integral": round(integral_ms / K, 4), "cascade": round(cascade_ms / K, 4),
                                    "cascade_passes": [round(x / K, 4) for x in pass_ms],
@@ -410,6 +442,39 @@ def main() -> int:
             print("bench.py: PARITY FAILURE on the CPU sample", file=sys.stderr)
             return 4
     return 0
+
+
+def three_states(env, call, torch, timed=8) -> dict:
+    """A workload whose chain balance the library finds by feedback, in the three states a caller can meet it: `static` — the
+    feedback switched off, the batch-size defaults —, `first_call` — feedback on, nothing known: the one-shot caller's time,
+    plan building included —, and `settled` — after the search, whose length is reported (`feedback_calls`, measured by the
+    library; `calls_until_settled` counts every call made meanwhile)."""
+    pct = lambda v, q: float(np.percentile(np.asarray(v), q))
+
+    def time_calls(k):
+        lat, r = [], None
+        for _ in range(k):
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            r = call()
+            lat.append((time.perf_counter() - t) * 1e3)
+        return lat, r
+    env.configure("auto_balance", "0")
+    time_calls(3)
+    static, r = time_calls(timed)
+    static_split = r.tile_split
+    env.configure("auto_balance", "reset")       # forget every workload, feedback on again
+    env.configure("auto_balance", "1")
+    first, r = time_calls(1)
+    n_calls = 1
+    while r.balance_state == 1 and n_calls < 64:
+        r = call()
+        n_calls += 1
+    settled, r = time_calls(timed)
+    return {"static_ms_p50": round(pct(static, 50), 3), "static_tile_split": round(static_split, 3),
+            "first_call_ms": round(first[0], 3), "settled_ms_p50": round(pct(settled, 50), 3),
+            "settled_tile_split": round(r.tile_split, 3), "feedback_calls": int(r.balance_calls), "calls_until_settled": n_calls,
+            "balance_state": int(r.balance_state), "detections": len(r.rects)}
 
 
 def run_extras(env, casc_alt, frames_h, which, torch) -> dict:
@@ -444,17 +509,23 @@ def run_extras(env, casc_alt, frames_h, which, torch) -> dict:
         try:
             for b in bufs:
                 b[...] = frames_h
-            st.submit(bufs[0])
-            n = 8
+            st.submit(bufs[0])        # warm-up: one whole batch through the stream, collected before the clock starts
+            st.collect()
+            n = 12
             torch.cuda.synchronize()
             t = time.perf_counter()
-            for k in range(1, n + 1):
+            # n batches, every one of them SUBMITTED AND COLLECTED inside the bracket (round 3 collected n - 1 of the n it timed
+            # and divided by n: 8/7 too fast).  The first upload of the bracket has nothing to hide behind: 1/n of the H2D time
+            # is in the figure, as it is for any caller who starts a stream.
+            st.submit(bufs[0])
+            for k in range(1, n):
                 st.submit(bufs[k % 2])
                 st.collect()
-            dt = (time.perf_counter() - t) / n
             st.collect()
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t) / n
             extra["config3_host_frames"] = {"workload": f"{B}x{W}x{H} frames in page-locked host memory, double-buffered vj_stream "
-                                                        "(H2D of batch k+1 overlaps the kernels of batch k)",
+                                                        f"(H2D of batch k+1 overlaps the kernels of batch k), {n} batches submitted and collected inside the bracket",
                                             "ms_per_step": round(dt * 1e3, 3),
                                             "windows_per_s": round(casc_alt.count_windows(W, H) * B / dt, 1)}
         finally:
@@ -467,17 +538,10 @@ def run_extras(env, casc_alt, frames_h, which, torch) -> dict:
         d = torch.from_numpy(f).cuda()
         df = DeviceFrames.from_torch(d)
         ws = c.count_windows(4096, 4096)
-        for _ in range(30):      # (a 16-megapixel call is a workload whose chain balance the first calls settle)
-            env.detect(c, df)
-        lat = []
-        for _ in range(8):
-            torch.cuda.synchronize()
-            t = time.perf_counter()
-            r = env.detect(c, df)
-            lat.append((time.perf_counter() - t) * 1e3)
-        extra["config4"] = {"workload": "1x4096x4096 (blocks), frontalface_alt_tree, frame resident in HBM, 8 calls",
-                            "ms_p50": round(pct(lat, 50), 3), "windows_per_frame": ws,
-                            "windows_per_s": round(ws / (pct(lat, 50) * 1e-3), 1), "detections": len(r.rects)}
+        three = three_states(env, lambda: env.detect(c, df), torch, timed=8)
+        extra["config4"] = {"workload": "1x4096x4096 (blocks), frontalface_alt_tree, frame resident in HBM, 8 calls per state",
+                            "ms_p50": three["settled_ms_p50"], "windows_per_frame": ws,
+                            "windows_per_s": round(ws / (three["settled_ms_p50"] * 1e-3), 1), "detections": three["detections"], **three}
         del d
     if "5" in which:
         face, eye = Cascade.load("frontalface_alt2"), Cascade.load("eye")
@@ -489,20 +553,20 @@ def run_extras(env, casc_alt, frames_h, which, torch) -> dict:
         ws = face.count_windows(1280, 720)
         for tag, p1, what in (("config5", default_params(min_neighbors=3), "the faces (candidates grouped on the device, minNeighbors 3)"),
                               ("config5_raw_candidates", default_params(), "every raw face candidate")):
-            for _ in range(24):      # (the first cascade's chain balance is found over the workload's first calls)
-                env.detect_chain(face, eye, df, p1)
-            lat = []
-            for _ in range(3):
-                torch.cuda.synchronize()
-                t = time.perf_counter()
-                r1, r2 = env.detect_chain(face, eye, df, p1)
-                lat.append((time.perf_counter() - t) * 1e3)
+            last = {}
+
+            def call():
+                last["r"] = env.detect_chain(face, eye, df, p1)
+                return last["r"][0]
+            three = three_states(env, call, torch, timed=3)
+            r1, r2 = last["r"]
+            ms = three["settled_ms_p50"]
             extra[tag] = {"workload": "256x1280x720 (faces/noise/smooth/blocks), frontalface_alt2 -> haarcascade_eye inside " + what +
                                       ", regions handed over on the device (vj_detect_chain), frames resident in HBM",
-                          "ms_per_step": round(pct(lat, 50), 3), "frames_per_s": round(n / (pct(lat, 50) * 1e-3), 1),
-                          "face_windows_per_s": round(ws * n / (pct(lat, 50) * 1e-3), 1),
+                          "ms_per_step": ms, "frames_per_s": round(n / (ms * 1e-3), 1),
+                          "face_windows_per_s": round(ws * n / (ms * 1e-3), 1),
                           "face_regions": len(r1.rects), "eye_candidates": len(r2.rects),
-                          "grouping_and_second_cascade_ms": round(r2.cascade_ms, 3)}
+                          "grouping_and_second_cascade_ms": round(r2.cascade_ms, 3), **three}
         del d
     return extra
 

@@ -99,7 +99,8 @@ class _Timing(C.Structure):
     _fields_ = [("integral_ms", C.c_float), ("cascade_ms", C.c_float), ("total_ms", C.c_float),
                 ("n_cascade_launches", C.c_int32), ("pass_ms", C.c_float * VJ_MAX_PASSES),
                 ("pass_stage_begin", C.c_int32 * VJ_MAX_PASSES), ("pass_stage_end", C.c_int32 * VJ_MAX_PASSES),
-                ("n_launches", C.c_int32), ("launch", _Launch * VJ_MAX_LAUNCHES), ("tile_split", C.c_float)]
+                ("n_launches", C.c_int32), ("launch", _Launch * VJ_MAX_LAUNCHES), ("tile_split", C.c_float),
+                ("balance_state", C.c_int32), ("balance_calls", C.c_int32)]
 
 
 class _Result(C.Structure):
@@ -329,6 +330,8 @@ class DetectResult:
     passes: list = None          # [(stage_begin, stage_end, ms)] per cascade pass
     launches: list = None        # per kernel launch: dict(kind, lds_class, stage_begin, stage_end, ms, lds_bytes, scales)
     tile_split: float = 0.0      # the chain balance the call's plan was built for
+    balance_state: int = 0       # 0 static, 1 the workload's feedback search is running, 2 finished
+    balance_calls: int = 0       # calls the search has measured so far
 
     @property
     def match_count(self) -> int:
@@ -512,7 +515,8 @@ class Environment:
                                       lds_bytes=int(l.lds_bytes),
                                       scales=[k for k in range(127) if (l.scale_mask[k >> 6] >> (k & 63)) & 1],
                                       stage_entered=[int(v) for v in l.stage_entered[:cascade.info.n_stages]])
-                                 for l in list(t.launch)[:int(t.n_launches)]], float(t.tile_split))
+                                 for l in list(t.launch)[:int(t.n_launches)]], float(t.tile_split),
+                                int(t.balance_state), int(t.balance_calls))
         finally:
             lib.vj_result_free(C.byref(res))
 

@@ -29,6 +29,22 @@ void set_error(const char* fmt, ...) {
 
 static std::atomic<uint64_t> g_uid{1};
 
+void finish_cascade(vj_cascade* c) {
+    c->uid = g_uid++;
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void* data, size_t n) {
+        const unsigned char* b = (const unsigned char*)data;
+        for (size_t i = 0; i < n; ++i) { h ^= b[i]; h *= 1099511628211ull; }
+    };
+    mix(&c->win_w, 4);
+    mix(&c->win_h, 4);
+    mix(c->stages.data(), c->stages.size() * sizeof(vj_stage_desc));
+    mix(c->trees.data(), c->trees.size() * sizeof(vj_tree_desc));
+    mix(c->nodes.data(), c->nodes.size() * sizeof(vj_node_desc));
+    mix(c->alpha.data(), c->alpha.size() * sizeof(float));
+    c->content_hash = h;
+}
+
 // ---------------------------------------------------------------- tiny XML DOM
 struct XmlNode {
     std::string name;
@@ -389,7 +405,7 @@ int vj_cascade_load_xml(const char* path, vj_cascade** out) {
     rc = from_xml(root->kids[0].get(), c.get());
     if (rc) return rc;
     c->notice = "Converted from OpenCV " + root->kids[0]->name + ".xml. Original notice:\n" + xp.first_comment;
-    c->uid = g_uid++;
+    vj::finish_cascade(c.get());
     *out = c.release();
     return VJ_OK;
 }
@@ -504,7 +520,7 @@ int vj_cascade_load(const char* path, vj_cascade** out) {
     p += c->nodes.size() * sizeof(vj_node_desc);
     memcpy(c->alpha.data(), p, c->alpha.size() * sizeof(float));
     if ((rc = validate_cascade(*c, path))) return rc;
-    c->uid = g_uid++;
+    vj::finish_cascade(c.get());
     *out = c.release();
     return VJ_OK;
 }
@@ -539,7 +555,7 @@ int vj_cascade_from_arrays(int win_w, int win_h, const vj_stage_desc* stages, in
     }
     int rc = validate_cascade(*c, "vj_cascade_from_arrays");
     if (rc) return rc;
-    c->uid = g_uid++;
+    vj::finish_cascade(c.get());
     *out = c.release();
     return VJ_OK;
 }

@@ -573,47 +573,99 @@ static int small_frame_class(const vj_env* e, int W, int H, int n_frames) {
 }
 
 // The workload whose chain balance is being found (or was found) by feedback: batches of >= 8 frames through vj_detect.
+static vj_env::BalanceKey balance_key(const vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, int n_frames) {
+    return vj_env::BalanceKey(vj_env::PlanKey(c->content_hash, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
+                                              p.scale_mask[1], p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64), 0u),
+                              e->balance_class(n_frames));
+}
+
 static vj_env::Balance* balance_of(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, int n_frames, bool create) {
     // (calls of at least eight frames or sixteen megapixels: below that a call is a millisecond and its time says little)
     if (!e->auto_balance || e->tile_split_set || !e->concurrent || n_frames >= (1 << 20) ||
         (n_frames < 8 && (uint64_t)W * (uint64_t)H * (uint64_t)n_frames < 16000000ull))
         return nullptr;
-    const vj_env::BalanceKey key(vj_env::PlanKey(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
-                                                 p.scale_mask[1], p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64), 0u),
-                                 n_frames);
+    const vj_env::BalanceKey key = balance_key(e, c, W, H, p, n_frames);
     auto it = e->balance.find(key);
-    if (it != e->balance.end()) return &it->second;
+    if (it != e->balance.end()) {
+        it->second.last_used = ++e->balance_tick;
+        return &it->second;
+    }
     if (!create) return nullptr;
-    if (e->balance.size() > 256) e->balance.clear();   // bounded
+    while (e->balance.size() >= 256) {   // bounded: the least recently used workload goes (a frozen result is cheap to find again)
+        auto lru = e->balance.begin();
+        for (auto i = e->balance.begin(); i != e->balance.end(); ++i)
+            if (i->second.last_used < lru->second.last_used) lru = i;
+        e->balance.erase(lru);
+    }
     vj_env::Balance b;
     b.cur = b.best = e->split_for(n_frames, p);
+    b.n_ref = n_frames;
+    b.last_used = ++e->balance_tick;
     return &(e->balance[key] = b);
 }
 
-// One more measured call (cascade kernels' time, uncounted variants) of a workload that is still being balanced.  Three
-// calls per candidate, the first of which pays for the plan: the fastest counts.  Steps of a quarter of a scale; a move needs 0.7 %.
+// What a call of n_frames frames runs: the candidate under test when it is one of the workload's sampling calls (the class's
+// reference size, search not finished), else the best split known.
+struct BalanceChoice {
+    float split;
+    int thr;
+    bool candidate;
+};
+static BalanceChoice balance_choice(const vj_env::Balance* b, int n_frames) {
+    if (b->phase != 3 && n_frames == b->n_ref) return BalanceChoice{b->cur, b->thr, b->cur != b->best || b->phase == 4};
+    return BalanceChoice{b->best, b->phase == 4 ? 0 : b->thr, false};
+}
+
+// Called once per vj_detect / vj_detect_chain call of a balanced workload, before its plan is looked up: bookkeeping, and the
+// reference size follows the traffic (a class whose reference size stopped coming — 32 calls of other sizes — restarts the
+// measurement of its current best at the size that does come; what was found so far stays the starting point).
+static void balance_touch(vj_env::Balance* b, int n_frames) {
+    ++b->calls_total;
+    if (b->phase == 3) return;
+    if (n_frames == b->n_ref) {
+        b->off_ref = 0;
+    } else if (++b->off_ref > 32) {
+        b->n_ref = n_frames;
+        b->off_ref = 0;
+        b->cur = b->best;
+        b->phase = 0;
+        b->samples = 0;
+        b->moved = 0;
+    }
+    if (balance_choice(b, n_frames).candidate) ++b->calls_on_candidate;
+}
+
+// One more measured call (cascade kernels' time per frame, uncounted variants, the class's reference batch size) of a workload
+// that is still being balanced.  Three calls per candidate — the first unrated (a new plan's tables were just uploaded: the
+// device idled), the faster of the other two counts — or two when both the unrated call and the first rated one were already
+// more than 3 % slower than the best: such a candidate is dropped at once.  Steps of a quarter of a scale; a move needs 0.7 %;
+// at most 40 calls per workload.
 static void balance_report(vj_env::Balance* b, float ms, bool try_thresholds) {
     if (!b || b->phase == 3 || !(ms > 0.0f)) return;
     ++b->calls;
+    bool early_drop = false;
     if (++b->samples == 1) {
         b->cand_ms = 1e30f;
+        b->first_slow = b->phase != 0 && ms > b->best_ms * 1.03f;
         return;
     }
     b->cand_ms = std::min(b->cand_ms, ms);
-    if (b->samples < 3) return;
+    if (b->samples == 2 && b->first_slow && b->phase != 0 && ms > b->best_ms * 1.03f) early_drop = true;
+    if (b->samples < 3 && !early_drop) return;
     b->samples = 0;
     const float step = 0.25f, max_split = 3.0f;
+    const int max_calls = 40;
     // the split is settled: one more candidate — the same split with the lower tile thresholds (how many scales the tile chain
     // can take at all: the better value depends on the frames' content, profiles/r03_notes.md #6e) — then the search ends
     // — and before that one probe a whole scale further: the response is not always convex (a scale split between the two
     // chains can cost more than the same scale moved entirely), and a climb in quarters stops at the first rise
     auto freeze = [&]() {
         b->cur = b->best;
-        if (!b->far_tried && b->best + 1.0f <= max_split && b->calls <= 60) {
+        if (!b->far_tried && b->best + 1.0f <= max_split && b->calls <= max_calls) {
             b->far_tried = true;
             b->cur = b->best + 1.0f;
             b->phase = 5;
-        } else if (try_thresholds && !b->thr_tried) {
+        } else if (try_thresholds && !b->thr_tried && b->calls <= max_calls) {
             b->thr_tried = true;
             b->thr = 1;
             b->phase = 4;
@@ -654,7 +706,7 @@ static void balance_report(vj_env::Balance* b, float ms, bool try_thresholds) {
         b->best_ms = b->cand_ms;
         b->moved = 1;
         const float next = b->phase == 1 ? b->cur + step : b->cur - step;
-        if (next < 0.0f || next > max_split || b->calls > 60) freeze();
+        if (next < 0.0f || next > max_split || b->calls > max_calls) freeze();
         else b->cur = next;
     } else if (b->phase == 1 && !b->moved && b->best >= step) {
         b->phase = 2;
@@ -664,11 +716,70 @@ static void balance_report(vj_env::Balance* b, float ms, bool try_thresholds) {
     }
 }
 
+// The found balances as text, one workload per line, so that another environment (or process) can start from them:
+//   vjbal1 <cascade content hash> W H min_w min_h max_w max_h <scale factor bits> <mask0> <mask1> <flags> <class> <split> <thr>
+static int balance_export(const vj_env* e, const char* path) {
+    FILE* f = fopen(path, "w");
+    if (!f) {
+        set_error("cannot write %s", path);
+        return VJ_ERR_IO;
+    }
+    for (const auto& kv : e->balance) {
+        const vj_env::PlanKey& k = std::get<0>(kv.first);
+        const vj_env::Balance& b = kv.second;
+        // (the last four fields are for the reader of the file: search state — 0 = nothing measured yet, 3 = finished —, calls of
+        // the workload, those that ran a split other than the best known, calls the search measured; import skips state 0)
+        fprintf(f, "vjbal1 %llx %d %d %d %d %d %d %x %llx %llx %x %d %.4f %d %d %u %u %d\n", (unsigned long long)std::get<0>(k), std::get<1>(k),
+                std::get<2>(k), std::get<3>(k), std::get<4>(k), std::get<5>(k), std::get<6>(k), std::get<7>(k), (unsigned long long)std::get<8>(k),
+                (unsigned long long)std::get<9>(k), std::get<10>(k), std::get<1>(kv.first), (double)b.best, b.phase == 4 ? 0 : b.thr, b.phase,
+                b.calls_total, b.calls_on_candidate, b.calls);
+    }
+    fclose(f);
+    return VJ_OK;
+}
+
+static int balance_import(vj_env* e, const char* path) {
+    FILE* f = fopen(path, "r");
+    if (!f) {
+        set_error("cannot read %s", path);
+        return VJ_ERR_IO;
+    }
+    char line[512];
+    int n_bad = 0;
+    while (fgets(line, sizeof(line), f)) {
+        unsigned long long hash, m0, m1;
+        int W, H, a, b2, c2, d, cls, thr, state = 3;
+        unsigned sf, flags;
+        double split;
+        if (line[0] == '#' || line[0] == '\n') continue;
+        if (sscanf(line, "vjbal1 %llx %d %d %d %d %d %d %x %llx %llx %x %d %lf %d %d", &hash, &W, &H, &a, &b2, &c2, &d, &sf, &m0, &m1, &flags, &cls,
+                   &split, &thr, &state) < 14 || !(split >= 0.0 && split <= 3.0) || cls < 1) {
+            ++n_bad;
+            continue;
+        }
+        if (state == 0) continue;
+        vj_env::Balance b;
+        b.cur = b.best = (float)split;
+        b.thr = thr ? 1 : 0;
+        b.phase = 3;          // frozen: an imported workload does not search again ("auto_balance" "reset" forgets it)
+        b.thr_tried = b.far_tried = true;
+        b.last_used = ++e->balance_tick;
+        e->balance[vj_env::BalanceKey(vj_env::PlanKey((uint64_t)hash, W, H, a, b2, c2, d, (uint32_t)sf, (uint64_t)m0, (uint64_t)m1, (uint32_t)flags, 0u), cls)] = b;
+    }
+    fclose(f);
+    if (n_bad) {
+        set_error("%s: %d lines are not balance records", path, n_bad);
+        return VJ_ERR_PARSE;
+    }
+    return VJ_OK;
+}
+
 static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, Plan** out, int n_frames = 1 << 20) {
     const vj_env::Balance* bal = balance_of(e, c, W, H, p, n_frames, false);
-    const float split = bal ? bal->cur : e->split_for(n_frames, p);
+    const BalanceChoice choice = bal ? balance_choice(bal, n_frames) : BalanceChoice{e->split_for(n_frames, p), 0, false};
+    const float split = choice.split;
     int small = small_frame_class(e, W, H, n_frames);
-    if (small == 0 && bal && bal->thr == 1 && !e->tile_thresholds_set) small = 3;   // the feedback's lower thresholds
+    if (small == 0 && choice.thr == 1 && !e->tile_thresholds_set) small = 3;   // the feedback's lower thresholds
     vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
                         p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64)) | ((uint32_t)small << 8), f2u(split));
     auto it = e->plans.find(key);
@@ -1484,6 +1595,26 @@ static int check_frames(const vj_image* frames, int n_frames, int* W_, int* H_, 
 
 }  // namespace vj
 
+// What every entry point that takes a vj_params checks before it plans anything (vj_detect, vj_detect_rois,
+// vj_detect_chain for both parameter sets, vj_stream_create): the same VJ_ERR_ARG everywhere, so that no path can reach a
+// kernel with a flag combination the plan does not describe (VJ_FLAG_GRID_F64 alone would give the region pass a position
+// table its launcher never binds).
+static int check_params(const vj_params& p) {
+    if (!(p.scale_factor > 1.0f)) {
+        set_error("scale_factor must be > 1");
+        return VJ_ERR_ARG;
+    }
+    if ((p.flags & VJ_FLAG_SKIP_LIST) && (p.flags & VJ_FLAG_SKIP_ROW)) {
+        set_error("VJ_FLAG_SKIP_LIST and VJ_FLAG_SKIP_ROW are two different loops of the reference: pick one");
+        return VJ_ERR_ARG;
+    }
+    if ((p.flags & VJ_FLAG_GRID_F64) && !(p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW))) {
+        set_error("VJ_FLAG_GRID_F64 names the block variant's two loops: combine it with VJ_FLAG_SKIP_ROW or VJ_FLAG_SKIP_LIST");
+        return VJ_ERR_ARG;
+    }
+    return VJ_OK;
+}
+
 static void drop_plans(vj_env* e);
 
 // Arguments of the region pass (roi_plan_units + cascade_roi_pass): `second` inside regions of the nf frames whose integral
@@ -1530,6 +1661,8 @@ static void fill_region_args(vj_env* e, Lane* L, Plan* pl2, const vj_cascade* se
     ca.identity_order = pl2->general ? 0u : 1u;
     ca.tree2 = 0u;
     ca.signed_mean = (p_second.flags & VJ_FLAG_SIGNED_MEAN) ? 1u : 0u;
+    ca.pos_mode = pl2->pos_mode;   // (0 on this path: check_params sends the f64 grids through the per-size plans; bound all the same)
+    ca.pos_tab = (const uint32_t*)pl2->d_pos_tab.p;
     ca.gather_pairs = 2u;   // regions are small: thin waves, latency-bound
     ca.sp_tail_max = (uint32_t)std::max(0, std::min(e->sp_tail_max, 48));
     ca.max_stage_nodes = pl2->max_stage_nodes;
@@ -2022,6 +2155,13 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         drop_plans(e);
         return VJ_OK;
     }
+    if (strcmp(key, "balance_exact") == 0) {
+        e->balance_exact = atoi(value) != 0;
+        e->balance.clear();
+        return VJ_OK;
+    }
+    if (strcmp(key, "balance_export") == 0) return balance_export(e, value);   // value: a file path
+    if (strcmp(key, "balance_import") == 0) return balance_import(e, value);
     if (strcmp(key, "auto_balance") == 0) {   // 1: find the chain balance of a batch workload from its first calls' times; "reset": start over
         if (strcmp(value, "reset") == 0) e->tile_split_set = false;
         else e->auto_balance = atoi(value) != 0;
@@ -2234,24 +2374,15 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
     if (!e || !c || !p || !out || n_frames < 0 || (n_frames > 0 && !frames)) return VJ_ERR_ARG;
     memset(out, 0, sizeof(*out));
     if (n_frames == 0) return VJ_OK;
-    if (!(p->scale_factor > 1.0f)) {
-        set_error("scale_factor must be > 1");
-        return VJ_ERR_ARG;
-    }
-    if ((p->flags & VJ_FLAG_SKIP_LIST) && (p->flags & VJ_FLAG_SKIP_ROW)) {
-        set_error("VJ_FLAG_SKIP_LIST and VJ_FLAG_SKIP_ROW are two different loops of the reference: pick one");
-        return VJ_ERR_ARG;
-    }
-    if ((p->flags & VJ_FLAG_GRID_F64) && !(p->flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW))) {
-        set_error("VJ_FLAG_GRID_F64 names the block variant's two loops: combine it with VJ_FLAG_SKIP_ROW or VJ_FLAG_SKIP_LIST");
-        return VJ_ERR_ARG;
-    }
+    int rc = check_params(*p);
+    if (rc) return rc;
     int W, H, CH;
-    int rc = check_frames(frames, n_frames, &W, &H, &CH);
+    rc = check_frames(frames, n_frames, &W, &H, &CH);
     if (rc) return rc;
     HIP_TRY(hipSetDevice(e->device));
     Plan* pl;
     vj_env::Balance* bal = balance_of(e, c, W, H, *p, n_frames, true);   // (created before the plan is looked up: it names the split)
+    if (bal) balance_touch(bal, n_frames);
     rc = get_plan(e, c, W, H, *p, &pl, n_frames);
     if (rc) return rc;
     const uint64_t max_frames = max_frames_per_subbatch(e, pl);
@@ -2274,11 +2405,13 @@ int vj_detect(vj_env* e, const vj_cascade* c, const vj_image* frames, int n_fram
         if (!any_tile_scale) {
             bal->cur = bal->best;
             bal->phase = 3;
-        } else if (!(p->flags & VJ_FLAG_COUNTERS) && (uint64_t)n_frames <= max_frames) {
-            balance_report(bal, out->timing.cascade_ms, !e->tile_thresholds_set);
+        } else if (!(p->flags & VJ_FLAG_COUNTERS) && (uint64_t)n_frames <= max_frames && n_frames == bal->n_ref) {
+            balance_report(bal, out->timing.cascade_ms / (float)n_frames, !e->tile_thresholds_set);
         }
     }
     out->timing.tile_split = pl->tile_split;
+    out->timing.balance_state = !bal ? 0 : bal->phase == 3 ? 2 : 1;
+    out->timing.balance_calls = bal ? bal->calls : 0;
     return build_result(pl, dets, n_frames, *p, out);
 }
 
@@ -2289,6 +2422,10 @@ int vj_detect_rois(vj_env* e, const vj_cascade* c, const vj_image* frames, int n
                    const vj_params* p, vj_result* out) {
     if (!e || !c || !p || !out || n_frames < 0 || n_rois < 0 || (n_rois > 0 && (!frames || !rois))) return VJ_ERR_ARG;
     memset(out, 0, sizeof(*out));
+    {
+        const int prc = check_params(*p);
+        if (prc) return prc;
+    }
     std::map<std::pair<int, int>, std::vector<int>> by_size;   // (w, h) -> ROI indices
     for (int i = 0; i < n_rois; ++i) {
         const vj_roi& r = rois[i];
@@ -2368,9 +2505,9 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
     memset(out_first, 0, sizeof(*out_first));
     memset(out_second, 0, sizeof(*out_second));
     if (n_frames == 0) return VJ_OK;
-    if (!(p_first->scale_factor > 1.0f) || !(p_second->scale_factor > 1.0f)) {
-        set_error("scale_factor must be > 1");
-        return VJ_ERR_ARG;
+    for (const vj_params* pp : {p_first, p_second}) {
+        const int prc = check_params(*pp);
+        if (prc) return prc;
     }
     if ((p_first->flags | p_second->flags) & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW)) {
         // the CPU variants' skip rules make a window's fate depend on its row's history inside ITS image: the first cascade runs
@@ -2394,6 +2531,7 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
     Plan *pl1, *pl2;
     // (the first cascade's chain balance is found by feedback as in vj_detect: its kernels run before the region pass starts)
     vj_env::Balance* bal = balance_of(e, first, W, H, *p_first, n_frames, true);
+    if (bal) balance_touch(bal, n_frames);
     if ((rc = get_plan(e, first, W, H, *p_first, &pl1, n_frames))) return rc;
     // the second cascade is planned for the frame's stride and every scale a region as large as the frame could use;
     // each region picks its own scales and grid on the device
@@ -2590,11 +2728,13 @@ int vj_detect_chain(vj_env* e, const vj_cascade* first, const vj_cascade* second
         if (!any_tile_scale) {
             bal->cur = bal->best;
             bal->phase = 3;
-        } else if (!(p_first->flags & VJ_FLAG_COUNTERS) && (uint64_t)n_frames <= max_frames) {
-            balance_report(bal, out_first->timing.cascade_ms, !e->tile_thresholds_set);
+        } else if (!(p_first->flags & VJ_FLAG_COUNTERS) && (uint64_t)n_frames <= max_frames && n_frames == bal->n_ref) {
+            balance_report(bal, out_first->timing.cascade_ms / (float)n_frames, !e->tile_thresholds_set);
         }
     }
     out_first->timing.tile_split = pl1->tile_split;
+    out_first->timing.balance_state = !bal ? 0 : bal->phase == 3 ? 2 : 1;
+    out_first->timing.balance_calls = bal ? bal->calls : 0;
     // the first result in its sorted order; regions are numbered by their position in it
     std::vector<uint32_t> rank;
     if (grouped) {   // frames in order, groups in cv::partition's class order: already the result's order
@@ -2671,8 +2811,7 @@ int vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int 
     if (!e || !c || !p || width <= 0 || height <= 0 || max_batch <= 0) return VJ_ERR_ARG;
     const int CH = channels <= 1 ? 1 : channels;
     if (CH != 1 && CH != 3 && CH != 4) return VJ_ERR_ARG;
-    if (!(p->scale_factor > 1.0f) || ((p->flags & VJ_FLAG_SKIP_LIST) && (p->flags & VJ_FLAG_SKIP_ROW)) ||
-        ((p->flags & VJ_FLAG_GRID_F64) && !(p->flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW)))) return VJ_ERR_ARG;
+    if (check_params(*p)) return VJ_ERR_ARG;
     if ((uint64_t)(width + 1) * (uint64_t)(height + 3) >= (1ull << 30)) {
         set_error("image too large");
         return VJ_ERR_LIMIT;
@@ -2693,7 +2832,7 @@ int vj_stream_create(vj_env* e, const vj_cascade* c, int width, int height, int 
     // (a chain balance already found for this workload by vj_detect's feedback is taken over; a stream does not search itself)
     const vj_env::Balance* bal = balance_of(e, c, width, height, *p, max_batch, false);
     TileThresholds sth{e->tile_min_windows, e->tile_accept_windows, e->tile_max_dwords_per_window};
-    if (bal && bal->phase == 3 && bal->thr == 1 && !e->tile_thresholds_set) sth = TileThresholds{std::min(384, sth.min_windows), std::min(384, sth.accept_windows), sth.max_dwords_per_window};
+    if (bal && balance_choice(bal, -1).thr == 1 && !e->tile_thresholds_set) sth = TileThresholds{std::min(384, sth.min_windows), std::min(384, sth.accept_windows), sth.max_dwords_per_window};
     int rc = build_plan(e, *c, width, height, *p, s->plan.get(), bal ? bal->best : e->split_for(max_batch, *p), sth);
     if (rc) {
         s->plan->release_device();

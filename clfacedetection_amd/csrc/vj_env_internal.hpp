@@ -216,18 +216,33 @@ struct vj_env {
     uint32_t roi_unit_cap = 0, roi_det_cap = 0;
     typedef std::tuple<uint64_t, int, int, int, int, int, int, uint32_t, uint64_t, uint64_t, uint32_t, uint32_t> PlanKey;
     std::map<PlanKey, std::unique_ptr<vj::Plan>> plans;
-    // Chain balance per workload (cascade, frame size, parameters, batch size): how much tile work goes to the
-    // global-gather chain (Plan::tile_split) is found by a short hill climb on the measured cascade time of the first
-    // calls and then frozen; vj_env_configure("tile_split", ...) or ("auto_balance", "0") keep the static values.
+    // Chain balance per workload (cascade, frame size, parameters, batch-size CLASS): how much tile work goes to the
+    // global-gather chain (Plan::tile_split) is found by a short hill climb on the measured cascade time of the workload's
+    // first calls and then frozen; vj_env_configure("tile_split", ...) or ("auto_balance", "0") keep the static values.
+    // The key names the cascade by CONTENT (two loads of one file share an entry; an exported table fits another process)
+    // and the batch size by class (8-15, 16-31, 32-63, >= 64 frames; below 8 — single large frames — the exact count): a
+    // service whose batch sizes vary searches four times, not once per size.  Only calls of the class's reference size
+    // (n_ref: the first size seen, re-anchored when it stops coming) run candidates and feed the search — times are compared
+    // per frame of ONE size —; every other call of the class runs the best split found so far.
     struct Balance {
-        float cur = 0, best = 0, best_ms = 0, cand_ms = 0;
+        float cur = 0, best = 0, best_ms = 0, cand_ms = 0;   // (times: ms per frame)
         int phase = 0;        // 0: measuring the start value, 1: climbing up, 2: climbing down, 3: frozen, 4: measuring the other tile thresholds, 5: probing a whole scale further
         int samples = 0, moved = 0, calls = 0;
         int thr = 0;          // 0: the environment's tile thresholds; 1: scales whose tiles hold >= 384 windows go to tiles too
         bool thr_tried = false, far_tried = false;
+        int n_ref = 0;        // frames per call of the calls that sample
+        int off_ref = 0;      // calls of other sizes since n_ref was last seen
+        bool first_slow = false;   // the candidate's unrated first call was already > 3 % slower than the best
+        uint64_t last_used = 0;    // (least recently used entries go first when the table is full)
+        uint32_t calls_total = 0, calls_on_candidate = 0;   // every call of the workload / those that ran a split other than the best known
     };
-    typedef std::tuple<PlanKey, int> BalanceKey;    // the plan key with split = 0, frames per call
+    typedef std::tuple<PlanKey, int> BalanceKey;    // the plan key with the cascade's content hash and split = 0, batch-size class
     std::map<BalanceKey, Balance> balance;
+    uint64_t balance_tick = 0;
+    bool balance_exact = false;   // key on the exact frame count, as round 3 did ("balance_exact": for the before / after of tools/balance_service.py)
+    int balance_class(int n_frames) const {
+        return balance_exact || n_frames < 8 ? n_frames : n_frames < 16 ? 8 : n_frames < 32 ? 16 : n_frames < 64 ? 32 : 64;
+    }
     bool auto_balance = true, tile_split_set = false;
     typedef std::tuple<uint64_t, int, int, int, int, uint64_t, int> CvPlanKey;   // cascade uid, W, H, min size, bits of the scale factor, call of <= 4 frames
     std::map<CvPlanKey, std::unique_ptr<vj::CvPlan>> cv_plans;

@@ -13,7 +13,9 @@ struct vj_cascade {
     std::vector<float>         alpha;
     std::string notice;   // license / provenance comment of the source XML
     uint64_t uid = 0;     // unique per loaded object; keys the env's plan cache
+    uint64_t content_hash = 0;   // FNV-1a of the window size and the four arrays: names the cascade across loads and processes
 };
+namespace vj { void finish_cascade(vj_cascade* c); }   // uid + content hash, once the arrays are final
 
 namespace vj {
 

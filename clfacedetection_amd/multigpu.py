@@ -10,7 +10,8 @@ independent given that frame's integral images.  So
     longest-first so that every rank keeps both of its chains busy);
 and the only collective is the final all-gather of the detection rectangles
 (torch.distributed: backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in the CPU
-tests).  Payloads are a few KB, so this is latency-, not bandwidth-bound.
+tests): ONE all-gather of fixed-capacity `[count | rects x cap]` blocks per step (RectGather).
+Payloads are a few KB, so this is latency-, not bandwidth-bound.
 """
 from __future__ import annotations
 
@@ -73,33 +74,78 @@ def plan(n_frames: int, window_counts: list[int], rank: int, world: int, window_
     return list(range(n_frames)), shard_scales(window_counts, rank, world, window_sides, base_side)
 
 
+class RectGather:
+    """The one collective of the N > 1 path: every rank contributes a fixed-capacity block
+    `[count | rects x cap]` (int32 rows of RECT_FIELDS; row 0 carries the count) and ONE all-gather moves all of them.  The
+    capacity persists across steps; when any rank's count exceeds it every rank sees that in the gathered headers, all of
+    them double the capacity the same way and repeat the step's collective — so a steady workload costs one collective and
+    one device-to-host copy per step (`n_collectives`, `last_ms`).  `device`: where the tensors live (the GPU for backend
+    "nccl" = RCCL, the CPU for gloo)."""
+
+    def __init__(self, device=None, group=None, cap: int = 1024):
+        import torch
+        self.device = device if device is not None else torch.device("cpu")
+        self.group = group
+        self.cap = max(1, int(cap))
+        self.n_collectives = 0
+        self.last_ms = 0.0
+        self.total_ms = 0.0
+        self._send = self._recv = None
+
+    def _buffers(self, world):
+        import torch
+        shape = (self.cap + 1, len(RECT_FIELDS))
+        if self._send is None or tuple(self._send.shape) != shape:
+            self._send = torch.zeros(shape, dtype=torch.int32, device=self.device)
+            self._recv = torch.zeros((world * shape[0], shape[1]), dtype=torch.int32, device=self.device)   # (ranks concatenated along dim 0: the form gloo accepts too)
+        return self._send, self._recv
+
+    def __call__(self, rects: np.ndarray) -> np.ndarray:
+        import time
+        import torch
+        import torch.distributed as dist
+        t0 = time.perf_counter()
+        world = dist.get_world_size(self.group)
+        if len(rects) and not np.array_equal(rects["weight"], np.rint(rects["weight"])):
+            raise ValueError("rectangle weights are neighbour counts: integers")
+        mine = np.stack([rects[f].astype(np.int32) for f in RECT_FIELDS], axis=1) if len(rects) else \
+            np.zeros((0, len(RECT_FIELDS)), np.int32)
+        while True:
+            send, recv = self._buffers(world)
+            block = np.zeros((self.cap + 1, len(RECT_FIELDS)), np.int32)
+            block[0, 0] = len(mine)
+            k = min(len(mine), self.cap)
+            block[1:1 + k] = mine[:k]
+            send.copy_(torch.from_numpy(block))          # (one host-to-device copy; CPU tensors: a memcpy)
+            dist.all_gather_into_tensor(recv, send, group=self.group)
+            self.n_collectives += 1
+            got = recv.cpu().numpy().reshape(world, self.cap + 1, len(RECT_FIELDS))   # (one device-to-host copy = the step's only synchronisation)
+            counts = got[:, 0, 0].astype(np.int64)
+            if int(counts.max(initial=0)) <= self.cap:
+                break
+            while self.cap < int(counts.max()):           # every rank sees the same counts: the same new capacity everywhere
+                self.cap *= 2
+            self._send = None
+        parts = [got[r, 1:1 + int(counts[r])] for r in range(world)]
+        allr = np.concatenate(parts) if parts else mine
+        out = np.zeros(len(allr), rects.dtype)
+        for i, f in enumerate(RECT_FIELDS):
+            out[f] = allr[:, i]
+        out = out[np.lexsort((out["x"], out["y"], out["scale_idx"], out["frame"]))]
+        self.last_ms = (time.perf_counter() - t0) * 1e3
+        self.total_ms += self.last_ms
+        return out
+
+
+_GATHERERS = {}
+
+
 def allgather_rects(rects: np.ndarray, device=None, group=None) -> np.ndarray:
-    """All-gather variable-length detection lists; every rank returns the same array,
-    sorted by (frame, scale_idx, y, x).  `rects` carries GLOBAL frame indices.
-
-    Two collectives: counts, then one padded int32 [max_count, 7] tensor per rank."""
-    import torch
-    import torch.distributed as dist
-
-    world = dist.get_world_size(group)
-    dev = device if device is not None else torch.device("cpu")
-    if len(rects) and not np.array_equal(rects["weight"], np.rint(rects["weight"])):
-        raise ValueError("rectangle weights are neighbour counts: integers")
-    mine = np.stack([rects[f].astype(np.int32) for f in RECT_FIELDS], axis=1) if len(rects) else \
-        np.zeros((0, len(RECT_FIELDS)), np.int32)
-    n = torch.tensor([len(mine)], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    cap = max(max(counts), 1)
-    pad = torch.zeros((cap, len(RECT_FIELDS)), dtype=torch.int32, device=dev)
-    if len(mine):
-        pad[:len(mine)] = torch.from_numpy(mine).to(dev)
-    bufs = [torch.zeros_like(pad) for _ in range(world)]
-    dist.all_gather(bufs, pad, group=group)
-    parts = [b[:c].cpu().numpy() for b, c in zip(bufs, counts)]
-    allr = np.concatenate(parts) if parts else mine
-    out = np.zeros(len(allr), rects.dtype)
-    for i, f in enumerate(RECT_FIELDS):
-        out[f] = allr[:, i]
-    return out[np.lexsort((out["x"], out["y"], out["scale_idx"], out["frame"]))]
+    """All-gather variable-length detection lists; every rank returns the same array, sorted by (frame, scale_idx, y, x).
+    `rects` carries GLOBAL frame indices.  One collective per call (RectGather; the gatherer and its capacity are kept per
+    (device, group))."""
+    key = (str(device), id(group))
+    g = _GATHERERS.get(key)
+    if g is None:
+        g = _GATHERERS[key] = RectGather(device, group)
+    return g(rects)

@@ -42,6 +42,8 @@ int main(int argc, char** argv) {
     CHECK(ncclCommInitAll(comms.data(), n_dev, devs.data()) == ncclSuccess);
 
     std::vector<std::vector<vj_rect>> gathered((size_t)n_dev);
+    int collectives[3] = {0, 0, 0};
+    float gather_ms[3] = {0, 0, 0};
     std::vector<std::thread> th;
     for (int rank = 0; rank < n_dev; ++rank)
         th.emplace_back([&, rank]() {
@@ -56,11 +58,23 @@ int main(int argc, char** argv) {
             for (uint32_t i = 0; i < r.count; ++i) r.rects[i].frame += first;   // global frame numbers
             hipStream_t st;
             CHECK(hipStreamCreateWithFlags(&st, hipStreamNonBlocking) == hipSuccess);
-            vj_rect* all = nullptr;
-            uint32_t n_all = 0;
-            CHECK(vj_rccl_allgather_rects(comms[(size_t)rank], st, r.rects, r.count, n_dev, &all, &n_all) == VJ_OK);
-            gathered[(size_t)rank].assign(all, all + n_all);
-            free(all);
+            // the gatherer lives across steps (a service would keep it next to its vj_env): ONE collective per step.  It starts
+            // with room for 4 rectangles per rank here so that the first step also shows the regrow path (every rank reads the
+            // same counts in the gathered headers and repeats the collective with the same larger blocks).
+            vj_rccl_gatherer g;
+            CHECK(vj_rccl_gatherer_init(&g, comms[(size_t)rank], st, 4) == VJ_OK);
+            CHECK(g.n_ranks == n_dev);
+            for (int step = 0; step < 3; ++step) {
+                vj_rect* all = nullptr;
+                uint32_t n_all = 0;
+                const uint64_t before = g.n_collectives;
+                CHECK(vj_rccl_gatherer_run(&g, r.rects, r.count, &all, &n_all) == VJ_OK);
+                if (step > 0) CHECK(g.n_collectives == before + 1);      // steady state: one ncclAllGather per step
+                if (rank == 0) collectives[step] = (int)(g.n_collectives - before), gather_ms[step] = g.last_ms;
+                gathered[(size_t)rank].assign(all, all + n_all);
+                free(all);
+            }
+            vj_rccl_gatherer_destroy(&g);
             vj_result_free(&r);
             (void)hipStreamDestroy(st);
             vj_env_destroy(env);
@@ -84,8 +98,9 @@ int main(int argc, char** argv) {
             ok = g[i].x == whole.rects[i].x && g[i].y == whole.rects[i].y && g[i].w == whole.rects[i].w && g[i].frame == whole.rects[i].frame &&
                  g[i].scale_idx == whole.rects[i].scale_idx;
     }
-    printf("multi_gpu_detect: %d device(s), rccl_ranks %d, %d frames, %u rectangles gathered on every rank: %s\n", n_dev, rccl_ranks, n_frames,
-           whole.count, ok ? "OK" : "MISMATCH");
+    printf("multi_gpu_detect: %d device(s), rccl_ranks %d, %d frames, %u rectangles gathered on every rank: %s; collectives per step %d %d %d, "
+           "gather %.3f %.3f %.3f ms\n", n_dev, rccl_ranks, n_frames, whole.count, ok ? "OK" : "MISMATCH", collectives[0], collectives[1],
+           collectives[2], gather_ms[0], gather_ms[1], gather_ms[2]);
     vj_result_free(&whole);
     vj_env_destroy(env0);
     vj_cascade_free(casc);

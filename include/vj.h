@@ -264,6 +264,9 @@ typedef struct vj_timing {     /* HIP-event times of the last vj_detect, ms     
     vj_launch launch[VJ_MAX_LAUNCHES];       /* each with its own HIP events    */
     float tile_split;          /* vj_detect: scales' worth of tile work the plan of this call gave to the global-gather
                                   chain ("tile_split"; found per workload by feedback unless configured) */
+    int32_t balance_state;     /* 0: static balance (no feedback for this call); 1: the workload's feedback search is still
+                                  running; 2: finished — the workload runs its best split from now on */
+    int32_t balance_calls;     /* calls the search has measured so far for this workload (at most 40) */
 } vj_timing;
 
 typedef struct vj_result {

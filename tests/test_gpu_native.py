@@ -50,6 +50,8 @@ def test_native_multi_gpu_host_with_rccl(lib, tmp_path):
     import re
     m = re.search(r"(\d+) device\(s\), rccl_ranks (\d+)", out)
     assert m and m.group(1) == m.group(2)          # the all-gather spanned as many ranks as the box has devices (1 here)
+    m = re.search(r"collectives per step (\d+) (\d+) (\d+)", out)      # 4 slots at first: one regrow, then ONE collective per step
+    assert m and int(m.group(1)) in (1, 2) and m.group(2) == m.group(3) == "1", out
     print(out.strip().splitlines()[-1])
 
 

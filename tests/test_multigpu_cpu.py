@@ -109,8 +109,16 @@ def _worker(rank, world, port, mode, q):
             if my_scales is None or int(d["scale_idx"]) in my_scales:
                 rows.append((d["x"], d["y"], d["w"], d["h"], float(3 + (int(d["x"]) + int(d["y"])) % 5), f, d["scale_idx"]))   # a neighbour count
     mine = np.array(rows, RECT_DTYPE) if rows else np.zeros(0, RECT_DTYPE)
-    allr = multigpu.allgather_rects(mine)
-    q.put((rank, allr.tolist(), len(mine)))
+    # the single-collective form (fixed-capacity [count | rects x cap] blocks): a capacity of 4 rows overflows
+    # on the first step — every rank regrows the same way and repeats the collective —, the second step of the same
+    # workload then costs exactly one collective
+    g = multigpu.RectGather(cap=4)
+    allr = g(mine)
+    first_step = g.n_collectives
+    again = g(mine)
+    assert np.array_equal(allr, again) and g.n_collectives == first_step + 1 and g.cap >= len(mine)
+    assert np.array_equal(multigpu.allgather_rects(mine), allr)      # the module-level wrapper: same list
+    q.put((rank, allr.tolist(), len(mine), first_step))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -139,6 +147,7 @@ def test_two_ranks_reproduce_single_process(oracle, cascades, mode):
         r, _ = oracle.detect(a, frames[f])
         want += [(int(d["x"]), int(d["y"]), int(d["w"]), int(d["h"]), float(3 + (int(d["x"]) + int(d["y"])) % 5), f, int(d["scale_idx"])) for d in r]
     assert len(want) > 0
-    for rank, allr, n_mine in got:
+    for rank, allr, n_mine, first_step in got:
         assert [(x, y, w, h, wt, fr, sc) for (x, y, w, h, wt, fr, sc) in allr] == want      # weights (neighbour counts) travel too
+        assert first_step == (2 if max(g[2] for g in got) > 4 else 1)      # one regrow at most, decided identically on every rank
     assert sum(g[2] for g in got) == len(want)      # shards are disjoint
