@@ -104,6 +104,37 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
             ++tree_prefix;
     }
     pl->tree_prefix = tree_prefix;
+    // Is the rest of the tree a sequence of chains (CvChainDev)?  A chain is a run of sweep positions whose pass edges follow
+    // the order and end in an accept, whose rejects all go to ONE place: nowhere (final) or the first stage of the NEXT chain.
+    if (is_tree && tree_prefix != 0u && prog.on_pass[order[tree_prefix - 1u]] == (int)order[tree_prefix]) {
+        CvChainDev ch;
+        memset(&ch, 0, sizeof(ch));
+        bool ok = true;
+        uint32_t b = tree_prefix;
+        while (b < order.size() && ok) {
+            if (ch.n == 4u) { ok = false; break; }
+            const int f = prog.on_fail[order[b]];
+            uint32_t e2 = b;
+            while (true) {
+                const uint32_t sid = order[e2];
+                if (prog.on_fail[sid] != f) { ok = false; break; }
+                const int np = prog.on_pass[sid];
+                ++e2;
+                if (np == STAGE_ACCEPT) break;
+                if (e2 >= order.size() || np != (int)order[e2]) { ok = false; break; }
+            }
+            if (!ok) break;
+            ch.begin[ch.n] = b;
+            ch.end[ch.n] = e2;
+            if (f != STAGE_REJECT) {
+                if (e2 < order.size() && f == (int)order[e2]) ch.chained |= 1u << ch.n;   // rejects start the next chain
+                else ok = false;
+            }
+            ++ch.n;
+            b = e2;
+        }
+        if (ok && ch.n != 0u && !((ch.chained >> (ch.n - 1u)) & 1u)) pl->chains = ch;
+    }
     // (a stage tree's row kernel evaluates the whole tree at every grid position and is far slower per window than the tiles'
     // prefix: trees send every scale they can to tiles and leave the row kernel two workgroups per CU)
     pl->row_blocks = is_tree ? e->cv_row_blocks_tree : e->cv_row_blocks;
@@ -280,6 +311,8 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
         for (size_t k = 0; k < hs.size(); ++k) {
             CvScaleDev& sd = scales[k];
             if (sd.tile_th == 0u) continue;
+            sd.tq_slot = pl->n_tile_scales;
+            sd.tq_win_first = (uint32_t)std::min<uint64_t>(pl->tile_windows, 0xffffffffull);
             ++pl->n_tile_scales;
             pl->tile_windows += (uint64_t)sd.end_x * sd.end_y;
             sd.bits_base = word;
@@ -430,7 +463,8 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
     DevBuf& d_det = e->d_cv_det;
     DevBuf& d_counts = e->d_cv_counts;
     // counters: stage_entered[VJ_MAX_STAGES] | visited | ... | detection count | pad | 4 x 8 tile ticket counters
-    const size_t counts_bytes = 2 * VJ_MAX_STAGES * sizeof(uint64_t) + 16 + 4 * 8 * sizeof(uint32_t) + 16;   // ... | tree-queue count
+    // ... | 64 tree-queue counters (one per tile scale) | chain-pass ticket
+    const size_t counts_bytes = 2 * VJ_MAX_STAGES * sizeof(uint64_t) + 16 + 4 * 8 * sizeof(uint32_t) + 64 * sizeof(uint32_t) + 16;
     if ((rc = d_counts.ensure(counts_bytes))) return rc;
 
     const bool count = (p->flags & VJ_FLAG_COUNTERS) != 0;
@@ -474,6 +508,12 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             a.det_count = (uint32_t*)((unsigned long long*)d_counts.p + 2 * VJ_MAX_STAGES);
             a.det_cap = det_cap;
             a.stage_entered = (unsigned long long*)d_counts.p;
+            if (is_tree && pl->chains.n != 0u && !count && e->cv_tree_chains) {   // the rows kernel sweeps the chains too (cv_chain_sweep): a fail list per wave
+                a.chains = pl->chains;
+                const size_t waves = (size_t)std::max(1, e->n_cu * 4) * CV_WAVES_PER_BLOCK;
+                if ((rc = e->d_cv_fail_rows.ensure(waves * CV_QCAP * 16u))) return rc;
+                a.fail_scratch = e->d_cv_fail_rows.p;
+            }
             HIP_TRY(hipEventRecord(e->lane0.ev[2], e->stream));
             int hrc = 0;
             // (a stage tree's tile path leaves no per-stage counts of the visited windows: counted calls walk the rows)
@@ -487,8 +527,22 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 if ((rc = e->d_cv_accept.ensure(bits_bytes))) return rc;
                 // room for 1 / 2^shift of the tile windows (a few percent survive the prefix); an overflow halves the shift and
                 // runs the call again; a forced capacity (tests) falls back to the rows instead
-                tq_cap = (uint32_t)std::min<uint64_t>(((pl->tile_windows * (uint64_t)nf) >> e->cv_tq_shift) + 4096u, 1ull << 28);
+                // (the shift belongs to the PLAN: one survivor-heavy workload does not make every later call allocate more)
+                if (pl->tq_shift < 0) pl->tq_shift = e->cv_tq_shift;
+                const bool chain_pass = pl->chains.n != 0u && pl->n_tile_scales <= 64u && e->cv_tree_queue_cap <= 0 && e->cv_tree_chains;
+                const uint64_t want = chain_pass ? cv_tq_first((uint32_t)std::min<uint64_t>(pl->tile_windows, 0xffffffffull), pl->n_tile_scales, (uint32_t)nf, (uint32_t)pl->tq_shift) + 4096u
+                                                 : ((pl->tile_windows * (uint64_t)nf) >> pl->tq_shift) + 4096u;
+                tq_cap = (uint32_t)std::min<uint64_t>(want, 1ull << 28);
                 if (e->cv_tree_queue_cap > 0) tq_cap = (uint32_t)e->cv_tree_queue_cap;
+                {   // never more than a quarter of what the device has free: beyond that the rows take the call
+                    size_t free_b = 0, total_b = 0;
+                    if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)tq_cap * sizeof(CvTreeEntry) > e->d_cv_tq.cap &&
+                        (size_t)tq_cap * sizeof(CvTreeEntry) - e->d_cv_tq.cap > free_b / 4u) {
+                        rows_only = true;
+                        --attempt;
+                        continue;
+                    }
+                }
                 if ((rc = e->d_cv_tq.ensure((size_t)tq_cap * sizeof(CvTreeEntry)))) return rc;
                 HIP_TRY(hipMemsetAsync(e->d_skip_bits.p, 0, bits_bytes, e->stream));
                 HIP_TRY(hipMemsetAsync(e->d_cv_accept.p, 0, bits_bytes, e->stream));
@@ -510,6 +564,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 uint32_t* tq_count = tickets + 32;
                 CvTileArgs t;
                 memset(&t, 0, sizeof(t));
+                t.tq_shift = chain_pass ? (uint32_t)pl->tq_shift : 0xffffffffu;   // one sub-queue per scale, or one flat queue (cv_tree_walk)
                 t.sum = a.sum;
                 t.sqsum = a.sqsum;
                 t.table = a.table;
@@ -564,7 +619,20 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 w.det = a.det;
                 w.det_count = a.det_count;
                 w.det_cap = det_cap;
-                if (!hrc) hrc = launch_cv_tree_walk(w, std::max(1, e->n_cu * 4), e->stream);
+                if (chain_pass) {
+                    // the tree is made of chains: chunks of one scale's survivors, swept like a linear cascade (cv_chain_sweep)
+                    const int wb = std::max(1, e->n_cu * 2);
+                    w.tq_shift = (uint32_t)pl->tq_shift;
+                    w.n_scales = (uint32_t)scales.size();
+                    w.ticket = tq_count + 64;
+                    w.chains = pl->chains;
+                    w.total_waves = (uint32_t)wb * 4u;
+                    if ((rc = e->d_cv_fail_walk.ensure((size_t)w.total_waves * CV_TQ_CHUNK * sizeof(CvTreeEntry)))) return rc;
+                    w.fail_scratch = e->d_cv_fail_walk.p;
+                    if (!hrc) hrc = launch_cv_tree_chain_pass(w, wb, e->stream);
+                } else if (!hrc) {
+                    hrc = launch_cv_tree_walk(w, std::max(1, e->n_cu * 4), e->stream);
+                }
                 if (!hrc) {
                     CascadeArgs ra;
                     memset(&ra, 0, sizeof(ra));
@@ -666,10 +734,20 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             HIP_TRY(hipMemcpyAsync(h.data(), d_counts.p, counts_bytes, hipMemcpyDeviceToHost, e->stream));
             HIP_TRY(hipStreamSynchronize(e->stream));
             const uint32_t n_det = (uint32_t)(h[2 * VJ_MAX_STAGES] & 0xffffffffull);
-            const uint32_t n_tq = ((const uint32_t*)(h.data() + 2 * VJ_MAX_STAGES))[4 + 32];
-            if (tq_cap != 0u && n_tq > tq_cap) {   // more prefix survivors than the tree queue holds
-                if (e->cv_tree_queue_cap > 0 || e->cv_tq_shift == 0) rows_only = true;
-                else e->cv_tq_shift = std::max(0, e->cv_tq_shift - 2);      // 1/16 -> 1/4 -> every window
+            bool tq_overflow = false;
+            if (tq_cap != 0u) {   // more prefix survivors than the tree queue (or one scale's sub-queue) holds?
+                const uint32_t* tqc = (const uint32_t*)(h.data() + 2 * VJ_MAX_STAGES) + 4 + 32;
+                const bool per_scale = pl->chains.n != 0u && pl->n_tile_scales <= 64u && e->cv_tree_queue_cap <= 0 && e->cv_tree_chains;
+                if (!per_scale) {
+                    tq_overflow = tqc[0] > tq_cap;
+                } else {
+                    for (const CvScaleDev& sd : scales)
+                        if (sd.tile_th != 0u && (uint64_t)tqc[sd.tq_slot] > cv_tq_cap(sd.end_x, sd.end_y, (uint32_t)nf, (uint32_t)pl->tq_shift)) tq_overflow = true;
+                }
+            }
+            if (tq_overflow) {
+                if (e->cv_tree_queue_cap > 0 || pl->tq_shift <= 0) rows_only = true;
+                else pl->tq_shift = std::max(0, pl->tq_shift - 2);      // 1/16 -> 1/4 -> every window, for THIS plan
                 --attempt;
                 continue;
             }

@@ -116,6 +116,192 @@ __device__ __forceinline__ double cv_stage_sum_mode(rsrc_t img, rsrc_t timg, kpt
     return cv_stage_sum<TREES, false>(img, timg, tab, n_nodes, off, vnf);
 }
 
+// ------------------------------------------------------------------------ stage trees made of chains (CvChainDev)
+// The windows that survive a stage tree's linear prefix used to carry a target stage each and ride through ONE sweep of all
+// remaining stages in chunks of 64 — ever fewer lanes evaluating, 40 stages long.  A tree made of chains (frontalface_alt_tree)
+// is swept like a linear cascade instead: the population of a chain is compacted after every stage (full lanes while more than
+// 64 windows are left), its rejects are set aside and become the population of the next chain, and a population of at most
+// CV_TAIL_MAX windows evaluates a stage stump-parallel (lane = stump, the verdict bits replayed in stump order).  Arithmetic
+// and order of the additions per window are those of cv_stage_sum (tempcv.cpp:771-792, :834-861).
+
+// One stump stage on the lane's window, two stumps per step with all of their gathers in flight (a thin sweep pays a memory
+// round trip per step); the leaf values are added in stump order.  Stage trees never take the two_rects f64 branch
+// (StageDev::cv_f64 is 0 for them): int * float products widened to double (:783-788).
+__device__ __forceinline__ double cv_stage_sum_pairs(rsrc_t img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off, double vnf) {
+    double stage_sum = 0.0;
+    uint32_t j = 0;
+    if (n_nodes >= 2u) {
+        NodeRecDev ra = tab[0], rb = tab[1];
+        for (; j + 1u < n_nodes; j += 2u) {
+            const uint32_t ja = j + 2u < n_nodes ? j + 2u : j, jb = j + 3u < n_nodes ? j + 3u : j + 1u;
+            const NodeRecDev na = tab[ja], nb = tab[jb];   // the next pair travels meanwhile
+            const int32_t a0 = cv_calc_sum(img, off, ra[0], ra[3], ra[6]), a1 = cv_calc_sum(img, off, ra[1], ra[4], ra[7]);
+            const int32_t b0 = cv_calc_sum(img, off, rb[0], rb[3], rb[6]), b1 = cv_calc_sum(img, off, rb[1], rb[4], rb[7]);
+            double sa = (double)((float)a0 * __uint_as_float(ra[9]));
+            sa += (double)((float)a1 * __uint_as_float(ra[10]));
+            double sb = (double)((float)b0 * __uint_as_float(rb[9]));
+            sb += (double)((float)b1 * __uint_as_float(rb[10]));
+            const float wa2 = __uint_as_float(ra[11]), wb2 = __uint_as_float(rb[11]);
+            if (wa2 != 0.0f || wb2 != 0.0f) {   // uniform (an absent third rectangle has lt = da = db = 0: four reads of the origin)
+                const int32_t a2 = cv_calc_sum(img, off, ra[2], ra[5], ra[8]), b2 = cv_calc_sum(img, off, rb[2], rb[5], rb[8]);
+                if (wa2 != 0.0f) sa += (double)((float)a2 * wa2);
+                if (wb2 != 0.0f) sb += (double)((float)b2 * wb2);
+            }
+            stage_sum += (double)(sa < (double)__uint_as_float(ra[12]) * vnf ? __uint_as_float(ra[13]) : __uint_as_float(ra[14]));
+            stage_sum += (double)(sb < (double)__uint_as_float(rb[12]) * vnf ? __uint_as_float(rb[13]) : __uint_as_float(rb[14]));
+            ra = na;
+            rb = nb;
+        }
+    }
+    if (j < n_nodes) {
+        const NodeRecDev r = tab[j];
+        const double s = cv_node_sum<false>(img, img, r, off);
+        stage_sum += (double)(s < (double)__uint_as_float(r[12]) * vnf ? __uint_as_float(r[13]) : __uint_as_float(r[14]));
+    }
+    return stage_sum;
+}
+
+// One stump stage for a THIN population q[0, n), n <= CV_TAIL_MAX: lane j takes stump j of a block of 64 (its record arrives
+// with four coalesced 16-byte loads), every window is evaluated by all lanes at once (window offset uniform, corner offsets
+// per lane), a __ballot gives the block's verdict bits; then lane w adds window w's leaf values IN STUMP ORDER (the leaf values
+// come through the scalar cache).  Returns the pass mask (bit w: window w passes).  Upright features only (the caller checks).
+// `masks`: n x CV_TAIL_BLOCKS words of LDS scratch.
+template <typename E>
+__device__ __forceinline__ unsigned long long cv_tail_stage(rsrc_t img, const uint32_t* recs_g, kptr<NodeRecDev> tab, uint32_t n_nodes, double thr_stage,
+                                                            const E* q, uint32_t n, unsigned long long* masks, uint32_t lane) {
+    const uint32_t n_blocks = (n_nodes + 63u) >> 6;
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const uint32_t j = b * 64u + lane;
+        const bool active = j < n_nodes;
+        const uint4* rp = reinterpret_cast<const uint4*>(recs_g + (size_t)(active ? j : 0u) * 16u);
+        const uint4 r0 = rp[0], r1 = rp[1], r2 = rp[2], r3 = rp[3];
+        // CvNodeRec: lt[3] da[3] db[3] w[3] thr left right flags
+        const uint32_t lt0 = r0.x, lt1 = r0.y, lt2 = r0.z, da0 = r0.w, da1 = r1.x, da2 = r1.y, db0 = r1.z, db1 = r1.w, db2 = r2.x;
+        const float w0 = __uint_as_float(r2.y), w1 = __uint_as_float(r2.z), w2 = __uint_as_float(r2.w), thr_node = __uint_as_float(r3.x);
+        for (uint32_t w = 0; w < n; ++w) {
+            const E e = q[w];   // broadcast
+            const uint32_t uo = __builtin_amdgcn_readfirstlane(e.off);
+            auto rect = [&](uint32_t lt, uint32_t da, uint32_t db) {
+                return (int32_t)(ld_u32(img, lt, uo) - ld_u32(img, lt + da, uo) - ld_u32(img, lt + db, uo) + ld_u32(img, lt + da + db, uo));
+            };
+            const int32_t c0 = rect(lt0, da0, db0), c1 = rect(lt1, da1, db1), c2 = rect(lt2, da2, db2);
+            double sum = (double)((float)c0 * w0);
+            sum += (double)((float)c1 * w1);
+            const double with2 = sum + (double)((float)c2 * w2);
+            sum = w2 != 0.0f ? with2 : sum;
+            const unsigned long long m = __ballot(active && !(sum < (double)thr_node * e.vnf));   // bit: alpha[1] (right)
+            if (lane == 0) masks[w * CV_TAIL_BLOCKS + b] = m;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    const bool have = lane < n;
+    double stage_sum = 0.0;
+    kptr<uint32_t> leaf = reinterpret_cast<kptr<uint32_t>>(tab);   // record k: dwords 13 / 14 = left / right value
+    for (uint32_t b = 0; b < n_blocks; ++b) {
+        const unsigned long long m = masks[(have ? lane : 0u) * CV_TAIL_BLOCKS + b];
+        const uint32_t jn = min(64u, n_nodes - b * 64u);
+#pragma unroll 4
+        for (uint32_t k = 0; k < jn; ++k) {
+            const uint32_t j = b * 64u + k;
+            const float l = __uint_as_float(leaf[j * 16u + 13u]), r = __uint_as_float(leaf[j * 16u + 14u]);
+            stage_sum += (double)(((m >> k) & 1ull) != 0ull ? r : l);
+        }
+    }
+    __builtin_amdgcn_wave_barrier();   // every lane has read its masks
+    return __ballot(have && stage_sum >= thr_stage);
+}
+
+// 16- / 24-byte entries to and from the per-wave fail list in global memory.  The list is written with plain stores and read
+// back by the SAME wave: the reads go to the L2 (agent-scope relaxed loads: sc1), behind a drain of the wave's stores.
+template <typename E>
+__device__ __forceinline__ E cv_load_entry_l2(const E* p) {
+    static_assert(sizeof(E) % 8 == 0, "entries are multiples of 8 bytes");
+    E e;
+    unsigned long long* dst = reinterpret_cast<unsigned long long*>(&e);
+    const unsigned long long* src = reinterpret_cast<const unsigned long long*>(p);
+#pragma unroll
+    for (uint32_t k = 0; k < sizeof(E) / 8u; ++k) dst[k] = __hip_atomic_load(src + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return e;
+}
+
+// Sweep the chains of `ch` over the windows q[0, n) (LDS; entries carry .off and .vnf), all of one scale.  `final_(e, mine,
+// accepted)` is called in wave-uniform control flow for windows whose walk ends: lanes with `mine` set hold such a window.
+// `fail_g`: room for the population in global memory (this wave's own).
+template <bool TREES, typename E, typename Final>
+__device__ __forceinline__ void cv_chain_sweep(const CvChainDev& ch, kptr<StageDev> stages, rsrc_t img, rsrc_t timg, bool tail_ok, const uint32_t* table_g,
+                                               kptr<NodeRecDev> table, E* q, uint32_t n, E* fail_g, unsigned long long* masks, uint32_t lane,
+                                               Final final_) {
+    for (uint32_t k = 0; k < ch.n && n != 0u; ++k) {
+        const bool chained = ((ch.chained >> k) & 1u) != 0u;
+        uint32_t nf = 0;
+        for (uint32_t pos = ch.begin[k]; pos < ch.end[k] && n != 0u; ++pos) {
+            const uint32_t s = stages[pos].order;
+            const uint32_t first_node = stages[s].first_node, n_nodes = stages[s].n_nodes;
+            const double thr = (double)stages[s].threshold;
+            kptr<NodeRecDev> tab = table + first_node;
+            if (!TREES && tail_ok && n <= CV_TAIL_MAX && n_nodes >= 16u && n_nodes <= CV_TAIL_BLOCKS * 64u) {   // uniform
+                const unsigned long long pm = cv_tail_stage(img, table_g + (size_t)first_node * 16u, tab, n_nodes, thr, q, n, masks, lane);
+                const bool have = lane < n;
+                const E e = q[have ? lane : 0u];
+                const bool pass = ((pm >> lane) & 1ull) != 0ull;
+                const unsigned long long fm = __ballot(have && !pass);
+                if (fm != 0ull) {
+                    if (chained) {
+                        if (have && !pass) fail_g[nf + mbcnt(fm)] = e;
+                        nf += (uint32_t)__popcll(fm);
+                    } else {
+                        final_(e, have && !pass, false);
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (pass) q[mbcnt(pm)] = e;
+                n = (uint32_t)__popcll(pm);
+                __builtin_amdgcn_wave_barrier();
+                continue;
+            }
+            uint32_t m = 0;
+            for (uint32_t base = 0; base < n; base += 64u) {
+                const uint32_t i = base + lane;
+                const bool act = i < n;
+                const E e = q[act ? i : 0u];
+                bool pass = false;
+                if (act) {
+                    if (TREES) pass = cv_stage_sum<true, false>(img, timg, tab, n_nodes, e.off, e.vnf) >= thr;
+                    else if (tail_ok) pass = cv_stage_sum_pairs(img, tab, n_nodes, e.off, e.vnf) >= thr;
+                    else pass = cv_stage_sum<false, false>(img, timg, tab, n_nodes, e.off, e.vnf) >= thr;   // (tilted features)
+                }
+                const unsigned long long fm = __ballot(act && !pass);
+                if (fm != 0ull) {
+                    if (chained) {
+                        if (act && !pass) fail_g[nf + mbcnt(fm)] = e;
+                        nf += (uint32_t)__popcll(fm);
+                    } else {
+                        final_(e, act && !pass, false);
+                    }
+                }
+                const unsigned long long mask = __ballot(pass);
+                __builtin_amdgcn_wave_barrier();   // every lane has read its entry before any lane overwrites
+                if (pass) q[m + mbcnt(mask)] = e;
+                m += (uint32_t)__popcll(mask);
+                __builtin_amdgcn_wave_barrier();
+            }
+            n = m;
+        }
+        for (uint32_t base = 0; base < n; base += 64u) {   // passed the chain's last stage: accepted
+            const bool act = base + lane < n;
+            const E e = q[act ? base + lane : 0u];
+            final_(e, act, true);
+        }
+        if (!chained) break;
+        // the chain's rejects are the next chain's population
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        for (uint32_t i = lane; i < nf; i += 64u) q[i] = cv_load_entry_l2(fail_g + i);
+        __builtin_amdgcn_wave_barrier();
+        n = nf;
+    }
+}
+
 template <bool TREES, bool COUNT>
 __device__ __forceinline__ void cv_flush(const CvArgs& a, rsrc_t img, rsrc_t timg, kptr<NodeRecDev> table, CvQEntry* q, uint32_t& n,
                                          uint32_t slot, uint32_t frame, uint32_t lane) {
@@ -222,7 +408,22 @@ __global__ __launch_bounds__(CV_WAVES_PER_BLOCK * 64) void cv_profile_pass(CvArg
             while (prefix + 1u < a.n_order && stages[stages[prefix].order].on_fail == -2 &&
                    stages[stages[prefix].order].on_pass == (int32_t)stages[prefix + 1u].order)
                 ++prefix;
+            CvQEntry* fail_g = reinterpret_cast<CvQEntry*>(a.fail_scratch) + (size_t)rank * CV_QCAP;
             auto drain = [&](uint32_t seg0) {
+                if (a.chains.n != 0u) {
+                    // the tree is made of chains: compacting sweeps (every queued window sits at the first stage of chain 0)
+                    cv_chain_sweep<TREES>(a.chains, stages, img, timg, a.tilted == nullptr, a.table + (size_t)scales[slot].table_first * 16u, table, q, n_q,
+                                          fail_g, reinterpret_cast<unsigned long long*>(q + CV_TAIL_MAX), lane,
+                                          [&](const CvQEntry& e, bool mine, bool accepted) {
+                                              if (mine) {
+                                                  const uint32_t rel = (e.xy & 0xffffu) - seg0;
+                                                  atomicOr((accepted ? Aw : Fw) + (rel >> 6), 1ull << (rel & 63u));
+                                              }
+                                          });
+                    n_q = 0;
+                    __builtin_amdgcn_wave_barrier();
+                    return;
+                }
                 for (uint32_t base = 0; base < n_q; base += 64u) {
                     const bool act = base + lane < n_q;
                     const CvQEntry e = q[act ? base + lane : 0u];
@@ -475,6 +676,54 @@ __global__ __launch_bounds__(256) void cv_tree_emit(CvTreeArgs a) {
             if (hit && pos < a.det_cap) a.det[pos] = CvDet{(uint32_t)cv_round((double)(w * 64u + lane) * ystep), y, slot, frame};
         }
     }
+}
+
+// The same for a tree made of chains (CvTreeArgs::chains): one sub-queue per scale, so a wave draws chunks of CV_TQ_CHUNK windows
+// of ONE scale and sweeps the chains over them like a linear cascade (cv_chain_sweep).
+__global__ __launch_bounds__(256) void cv_tree_chain_pass(CvTreeArgs a) {
+    __shared__ CvTreeEntry lds_q[4 * CV_TQ_CHUNK];
+    const uint32_t lane = lane_id();
+    const uint32_t wib = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    CvTreeEntry* q = lds_q + wib * CV_TQ_CHUNK;
+    CvTreeEntry* fail_g = reinterpret_cast<CvTreeEntry*>(a.fail_scratch) + (size_t)(blockIdx.x * 4u + wib) * CV_TQ_CHUNK;
+    kptr<StageDev> stages = as_k(a.stages);
+    kptr<CvScaleDev> scales = as_k(a.scales);
+    kptr<uint32_t> counts = as_k(a.tq_count);
+    const rsrc_t img = make_rsrc(a.sum, a.sum_bytes);
+    while (true) {
+        uint32_t t = 0;
+        if (lane == 0) t = atomicAdd(a.ticket, 1u);
+        t = __builtin_amdgcn_readfirstlane(t);
+        // ticket -> (scale, chunk): the tile scales in order
+        uint32_t slot = 0, n_here = 0;
+        uint64_t first = 0;
+        for (; slot < a.n_scales; ++slot) {
+            if (scales[slot].tile_th == 0u) continue;
+            const uint64_t cap = cv_tq_cap(scales[slot].end_x, scales[slot].end_y, a.n_frames, a.tq_shift);
+            const uint32_t cnt = (uint32_t)min((uint64_t)counts[scales[slot].tq_slot], cap);
+            const uint32_t n_chunks = (cnt + CV_TQ_CHUNK - 1u) / CV_TQ_CHUNK;
+            if (t < n_chunks) {
+                first = cv_tq_first(scales[slot].tq_win_first, scales[slot].tq_slot, a.n_frames, a.tq_shift) + (uint64_t)t * CV_TQ_CHUNK;
+                n_here = min(CV_TQ_CHUNK, cnt - t * CV_TQ_CHUNK);
+                break;
+            }
+            t -= n_chunks;
+        }
+        if (slot == a.n_scales) return;   // every chunk is taken
+        for (uint32_t i = lane; i < n_here; i += 64u) q[i] = a.tq[first + i];
+        __builtin_amdgcn_wave_barrier();
+        kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + scales[slot].table_first;
+        cv_chain_sweep<false>(a.chains, stages, img, img, true, a.table + (size_t)scales[slot].table_first * 16u, table, q, n_here, fail_g,
+                              reinterpret_cast<unsigned long long*>(q + CV_TAIL_MAX), lane, [&](const CvTreeEntry& e, bool mine, bool accepted) {
+                                  if (mine) atomicOr((accepted ? a.accept : a.reject) + e.word, 1ull << (e.bit_slot & 63u));
+                              });
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+int launch_cv_tree_chain_pass(const CvTreeArgs& a, int n_blocks, void* stream_) {
+    hipLaunchKernelGGL(cv_tree_chain_pass, dim3(n_blocks), dim3(256), 0, (hipStream_t)stream_, a);
+    return (int)hipGetLastError();
 }
 
 int launch_cv_tree_walk(const CvTreeArgs& a, int n_blocks, void* stream_) {

@@ -611,8 +611,13 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
                 // survivors of the prefix: clear their reject bits, hand them to the tree walk; then the rows' words go out
                 cvt_barrier();   // (lds_F is complete: every wave wrote its rows before the first sweep barrier... and none re-packs any more)
                 if (n != 0u) {
+                    // one sub-queue per scale (a chunk of cv_tree_chain_pass then holds windows of one scale); tq_shift = ~0: one
+                    // flat queue (trees that are not made of chains: cv_tree_walk)
+                    const bool flat = a.tq_shift == 0xffffffffu;
+                    const uint64_t q_first = flat ? 0ull : cv_tq_first(scales[slot].tq_win_first, scales[slot].tq_slot, a.n_frames, a.tq_shift);
+                    const uint64_t q_cap = flat ? (uint64_t)a.tq_cap : cv_tq_cap(scales[slot].end_x, scales[slot].end_y, a.n_frames, a.tq_shift);
                     uint32_t g = 0;
-                    if (lane == 0) g = atomicAdd(a.tq_count, n);
+                    if (lane == 0) g = atomicAdd(a.tq_count + (flat ? 0u : scales[slot].tq_slot), n);
                     g = __builtin_amdgcn_readfirstlane(g);
                     for (uint32_t i = lane; i < n; i += 64u) {
                         const uint32_t raw = qo[i], tidx = raw >> 20, lo = (raw & CVT_OFF_MASK) >> 2;
@@ -620,8 +625,8 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
                         atomicAnd(&lds_F[ty], ~(1ull << tx));
                         const uint32_t ly = lo / pitch, lx = lo - ly * pitch;
                         const uint32_t ix = ix0 + tx, iy = iy0 + ty;
-                        if (g + i < a.tq_cap)
-                            a.tq[g + i] = CvTreeEntry{frame * frame_bytes4 + ((y0 + ly) * a.stride + (x0 + lx)) * 4u,
+                        if ((uint64_t)g + i < q_cap && q_first + g + i < (uint64_t)a.tq_cap)
+                            a.tq[q_first + g + i] = CvTreeEntry{frame * frame_bytes4 + ((y0 + ly) * a.stride + (x0 + lx)) * 4u,
                                                       frame * a.bits_frame_words + scales[slot].bits_base + iy * wpr + (ix >> 6), (ix & 63u) | (slot << 8),
                                                       0u, qv[i]};
                     }

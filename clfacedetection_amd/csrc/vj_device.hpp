@@ -327,8 +327,20 @@ struct CvScaleDev {
     uint32_t tile_rows;          // rows of the LDS image tile
     uint32_t tile_table_first;   // first CvNodeRec of this scale built with the tile's pitch
     uint32_t bits_base;          // first word of this scale in a frame's reject / visited bitmap ((end_x + 63) / 64 words per window row)
+    // stage trees on tiles: the survivors of the tree's linear prefix wait in one sub-queue per scale (a chunk of the walk
+    // then holds windows of ONE scale: full lanes, scalar table).  Sub-queue of this scale for n_frames frames: entries
+    // [tq_first(n_frames, shift), + tq_cap(n_frames, shift)) — see cv_tq_first / cv_tq_cap
+    uint32_t tq_win_first;       // grid windows of the tile scales before this one, per frame
+    uint32_t tq_slot;            // this scale's number among the tile scales
 };
-static_assert(sizeof(CvScaleDev) == 80, "CvScaleDev is 80 bytes");
+static_assert(sizeof(CvScaleDev) == 88, "CvScaleDev is 88 bytes");
+// one sub-queue: 1 / 2^shift of the scale's grid windows in the batch, at least 4096 entries
+__host__ __device__ inline uint64_t cv_tq_cap(uint32_t end_x, uint32_t end_y, uint32_t n_frames, uint32_t shift) {
+    return (((uint64_t)end_x * end_y * n_frames) >> shift) + 4096u;
+}
+__host__ __device__ inline uint64_t cv_tq_first(uint32_t tq_win_first, uint32_t tq_slot, uint32_t n_frames, uint32_t shift) {
+    return (((uint64_t)tq_win_first * n_frames) >> shift) + (uint64_t)tq_slot * 4096u;
+}
 
 struct CvDet {
     uint32_t x, y, slot, frame;
@@ -347,6 +359,20 @@ struct alignas(16) CvNodeRec {
 };
 static_assert(sizeof(CvNodeRec) == 64, "CvNodeRec must be 64 bytes");
 constexpr uint32_t CV_NODE_TILTED = 8u;
+
+// A stage tree whose part after the linear prefix is a sequence of CHAINS (tempcv.cpp:834-861 on frontalface_alt_tree: stages
+// 0-4, then 5, 7, ..., 39, whose rejects — anywhere — start 6, 8, ..., 46): chain k covers positions [begin[k], end[k]) of the
+// sweep order; passing a stage leads to the next position, passing the chain's last stage accepts; a reject inside chain k
+// continues at the first stage of chain k + 1 when bit k of `chained` is set, else it is final.  n == 0: the tree does not
+// have this shape (the per-lane target-stage walk is used).
+struct CvChainDev {
+    uint32_t n;
+    uint32_t begin[4], end[4];
+    uint32_t chained;
+};
+constexpr uint32_t CV_TAIL_MAX = 32;        // a population of at most this many windows finishes a stage stump-parallel (lane = stump)
+constexpr uint32_t CV_TAIL_BLOCKS = 8;      // ... stages of up to 8 x 64 nodes
+constexpr uint32_t CV_TQ_CHUNK = 256;       // windows per chunk of cv_tree_chain_pass
 
 constexpr int CV_WAVES_PER_BLOCK = 4;
 constexpr int VJ_MAX_STAGES_DEV = 64;  // == VJ_MAX_STAGES
@@ -372,6 +398,8 @@ struct CvArgs {
     uint32_t* det_count;
     uint32_t det_cap;
     unsigned long long* stage_entered;   // [VJ_MAX_STAGES] + [VJ_MAX_STAGES] = windows visited (border ones included)
+    CvChainDev chains;           // stage trees made of chains (else n = 0)
+    void* fail_scratch;          // ... CV_QCAP x 16 bytes per wave: where a chain's rejects wait for the next chain
 };
 
 int launch_cv_profile_pass(const CvArgs& a, bool trees, bool count, bool stage_tree, int n_blocks, void* stream);
@@ -404,8 +432,9 @@ struct CvTileArgs {
     unsigned long long* stage_entered;   // as CvArgs
     // stage trees (mode 2): the survivors of the tree's linear prefix wait here for cv_tree_walk
     struct CvTreeEntry* tq;
-    uint32_t* tq_count;
-    uint32_t tq_cap;
+    uint32_t* tq_count;          // one counter per tile scale (CvScaleDev::tq_slot), + [64]: entries that did not fit
+    uint32_t tq_cap;             // total entries of the queue buffer (all sub-queues)
+    uint32_t tq_shift;
 };
 // A window that passed the linear prefix of a stage tree inside a tile and walks the rest of the tree with global gathers.
 struct CvTreeEntry {
@@ -437,8 +466,16 @@ struct CvTreeArgs {
     CvDet* det;
     uint32_t* det_count;
     uint32_t det_cap;
+    // per-scale sub-queues + chains (cv_tree_chain_pass)
+    uint32_t tq_shift;           // sub-queue capacities: cv_tq_cap(.., n_frames, tq_shift)
+    uint32_t n_scales;
+    uint32_t* ticket;            // chunk ticket counter (zeroed before the launch)
+    CvChainDev chains;
+    void* fail_scratch;          // CV_TQ_CHUNK x 24 bytes per wave
+    uint32_t total_waves;
 };
 int launch_cv_tree_walk(const CvTreeArgs& a, int n_blocks, void* stream);
+int launch_cv_tree_chain_pass(const CvTreeArgs& a, int n_blocks, void* stream);
 int launch_cv_tree_emit(const CvTreeArgs& a, int n_blocks, void* stream);
 int prepare_cv_tile_kernels();   // per device: raise the dynamic-LDS cap
 int launch_skip_resolve(const CascadeArgs& a, int n_blocks, void* stream);   // reject bits -> visited bits (vj_kernels.hip)

@@ -1911,7 +1911,7 @@ void vj_env_destroy(vj_env* e) {
     drop_plans(e);
     for (DevBuf* b : {&e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_tilted, &e->d_out,
                       &e->d_skip_bits, &e->d_rois, &e->d_roi_units, &e->d_roi_det, &e->d_roi_tiles, &e->d_group, &e->d_cv_det, &e->d_cv_counts,
-                      &e->d_cv_accept, &e->d_cv_tq})
+                      &e->d_cv_accept, &e->d_cv_tq, &e->d_cv_fail_rows, &e->d_cv_fail_walk})
         b->release();
     e->lane0.destroy();
     for (DevBuf& b : e->d_q) b.release();
@@ -2014,6 +2014,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "tree_split_queues") == 0) {
         e->tree_split_queues = atoi(value) != 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "cv_tree_chains") == 0) {   // OpenCV profile, stage trees made of chains: compacting chain sweeps (1) or the per-lane walk (0)
+        e->cv_tree_chains = atoi(value) != 0;
         return VJ_OK;
     }
     if (strcmp(key, "cv_tree_queue_cap") == 0) {

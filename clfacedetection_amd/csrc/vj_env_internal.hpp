@@ -108,6 +108,9 @@ struct CvPlan {
     uint32_t n_tile_scales = 0, n_rows_rest = 0, bits_frame_words = 0, n_bit_segs = 0;
     int row_blocks = 1;               // workgroups per CU of cv_profile_pass next to the tiles
     uint32_t tree_prefix = 0;         // stage trees: stages of the linear prefix the tiles run (0: the cascade is linear)
+    CvChainDev chains = {};           // stage trees: the part after the prefix as chains (n = 0: not of that shape)
+    int tq_shift = -1;                // stage trees on tiles: the prefix survivors' sub-queues hold 1 / 2^shift of the tile windows
+                                      // (-1: the environment's start value; lowered for THIS plan when a sub-queue overflows)
     uint64_t tile_windows = 0;        // grid windows of the tile scales, per frame
     uint32_t class_first[3] = {0, 0, 0}, class_lds[2] = {0, 0};
     DevBuf d_tiles, d_rows_rest, d_bit_segs;
@@ -248,6 +251,7 @@ struct vj_env {
     std::map<CvPlanKey, std::unique_ptr<vj::CvPlan>> cv_plans;
     vj::DevBuf d_cv_det, d_cv_counts;   // vj_detect_opencv: detection list and counters
     vj::DevBuf d_cv_accept, d_cv_tq;    // ... stage trees on tiles: accept bitmap, the queue of the prefix's survivors
+    vj::DevBuf d_cv_fail_rows, d_cv_fail_walk;   // ... per-wave fail lists of the chain sweeps (rows kernel / chain pass)
     uint64_t plan_tick = 0;
     int plan_cache_max = 48;      // plans kept per environment; the least recently used one is released beyond that
                                   // (a stream of ROI sizes — eyes inside faces of any size — would otherwise grow
@@ -279,6 +283,7 @@ struct vj_env {
     int cv_tile_ws_max = 512;     // ... windows a tile carries into its wave-split finish
     int cv_row_blocks = 3;        // ... workgroups per CU of cv_profile_pass while it runs next to the tiles (their LDS budget shrinks with it)
     int cv_row_blocks_tree = 2, cv_tile_min_windows_tree = 512;   // ... the same two for stage trees (swept: profiles/r03_cv_sweeps.log)
+    bool cv_tree_chains = true;       // ... stage trees made of chains: compacting chain sweeps (0: the per-lane target-stage walk)
     int cv_tq_shift = 4;              // ... stage trees: the survivors' queue holds 1 / 2^shift of the tile windows (grows on overflow)
     int cv_tree_queue_cap = 0;        // ... stage trees: capacity of the prefix survivors' queue (0: a quarter of the tile windows)
     int cv_tile_min_windows0 = 2048;   // ... the same for the class with two tile workgroups per CU
