@@ -133,6 +133,7 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
             ++ch.n;
             b = e2;
         }
+        ch.tail_max = (uint32_t)std::max(0, std::min(e->cv_tail_max, (int)CV_TAIL_MAX));
         if (ok && ch.n != 0u && !((ch.chained >> (ch.n - 1u)) & 1u)) pl->chains = ch;
     }
     // (a stage tree's row kernel evaluates the whole tree at every grid position and is far slower per window than the tiles'
@@ -621,12 +622,13 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 w.det_cap = det_cap;
                 if (chain_pass) {
                     // the tree is made of chains: chunks of one scale's survivors, swept like a linear cascade (cv_chain_sweep)
-                    const int wb = std::max(1, e->n_cu * 2);
+                    const int wb = std::max(1, e->n_cu * std::max(1, std::min(e->cv_tree_chain_blocks, 4)));
                     w.tq_shift = (uint32_t)pl->tq_shift;
                     w.n_scales = (uint32_t)scales.size();
                     w.ticket = tq_count + 64;
                     w.chains = pl->chains;
                     w.total_waves = (uint32_t)wb * 4u;
+                    w.chunk = (uint32_t)std::max(64, std::min(e->cv_tree_chunk, (int)CV_TQ_CHUNK));
                     if ((rc = e->d_cv_fail_walk.ensure((size_t)w.total_waves * CV_TQ_CHUNK * sizeof(CvTreeEntry)))) return rc;
                     w.fail_scratch = e->d_cv_fail_walk.p;
                     if (!hrc) hrc = launch_cv_tree_chain_pass(w, wb, e->stream);

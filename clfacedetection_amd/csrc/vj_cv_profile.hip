@@ -239,7 +239,7 @@ __device__ __forceinline__ void cv_chain_sweep(const CvChainDev& ch, kptr<StageD
             const uint32_t first_node = stages[s].first_node, n_nodes = stages[s].n_nodes;
             const double thr = (double)stages[s].threshold;
             kptr<NodeRecDev> tab = table + first_node;
-            if (!TREES && tail_ok && n <= CV_TAIL_MAX && n_nodes >= 16u && n_nodes <= CV_TAIL_BLOCKS * 64u) {   // uniform
+            if (!TREES && tail_ok && n <= ch.tail_max && n_nodes >= 16u && n_nodes <= CV_TAIL_BLOCKS * 64u) {   // uniform
                 const unsigned long long pm = cv_tail_stage(img, table_g + (size_t)first_node * 16u, tab, n_nodes, thr, q, n, masks, lane);
                 const bool have = lane < n;
                 const E e = q[have ? lane : 0u];
@@ -701,10 +701,10 @@ __global__ __launch_bounds__(256) void cv_tree_chain_pass(CvTreeArgs a) {
             if (scales[slot].tile_th == 0u) continue;
             const uint64_t cap = cv_tq_cap(scales[slot].end_x, scales[slot].end_y, a.n_frames, a.tq_shift);
             const uint32_t cnt = (uint32_t)min((uint64_t)counts[scales[slot].tq_slot], cap);
-            const uint32_t n_chunks = (cnt + CV_TQ_CHUNK - 1u) / CV_TQ_CHUNK;
+            const uint32_t n_chunks = (cnt + a.chunk - 1u) / a.chunk;
             if (t < n_chunks) {
-                first = cv_tq_first(scales[slot].tq_win_first, scales[slot].tq_slot, a.n_frames, a.tq_shift) + (uint64_t)t * CV_TQ_CHUNK;
-                n_here = min(CV_TQ_CHUNK, cnt - t * CV_TQ_CHUNK);
+                first = cv_tq_first(scales[slot].tq_win_first, scales[slot].tq_slot, a.n_frames, a.tq_shift) + (uint64_t)t * a.chunk;
+                n_here = min(a.chunk, cnt - t * a.chunk);
                 break;
             }
             t -= n_chunks;

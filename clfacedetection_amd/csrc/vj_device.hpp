@@ -106,6 +106,9 @@ struct RoiTile {           // one LDS tile inside a region (cascade_tile_roi_pas
     uint32_t slot;
     uint32_t first;        // ix0 | iy0 << 16 in the region's own grid of this scale
     uint32_t nxy;          // the region's grid: nx | ny << 16
+    uint32_t twh;          // this tile's shape in windows, tw | th << 16: the region's grid cut into EQUAL parts no larger than the scale's
+                           // tile (a 51 x 51 grid in 64 x 32 tiles: two tiles of 51 x 26, not 51 x 32 + 51 x 19), and only the rows / columns
+                           // of the image such a tile needs are staged
 };
 
 // One block of <= 64 consecutive nodes of a stage (stump-parallel finish of the tile kernel).
@@ -163,6 +166,14 @@ struct CascadeArgs {
     uint32_t min_chunk;         // queue passes: smallest chunk of windows a wave draws (1..64)
     uint32_t thin_pass_spread;  // queue passes with fewer chunks than waves: only the first workgroups draw tickets (even load per CU)
     uint32_t q_slices;          // queue passes: a part's chunks are handed out in this many slices of every scale's range (frame-major order)
+    // Band-major queue pass (batches; linear cascades): the first pass records where every unit's survivors landed in their
+    // (scale, part) sub-queue (run_table[frame * n_units + unit] = {first entry, count}); the queue pass then draws GROUPS of
+    // consecutive units of one (image band, scale) — the host orders a frame's units by band first — in (frame, group) order:
+    // an XCD's waves work on one band of one frame across all scales before they move on (their gathers share an L2-sized
+    // part of the sum image), and nothing has to be sorted.
+    uint32_t* run_table;        // [n_frames * n_units][2] (null: not recorded)
+    const UnitDev* q_groups;    // {scale, first unit, units, band} (null: the queue pass walks the sub-queues chunk by chunk)
+    uint32_t n_q_groups;        // groups per frame
     QEntry*   q_out;            // survivor queue written by this pass (not the last)
     uint32_t* q_out_count;
     QEntry*   q_fail;           // stage trees: queue of the chain that takes this pass's rejects (else null)
@@ -369,10 +380,11 @@ struct CvChainDev {
     uint32_t n;
     uint32_t begin[4], end[4];
     uint32_t chained;
+    uint32_t tail_max;           // see CV_TAIL_MAX
 };
-constexpr uint32_t CV_TAIL_MAX = 32;        // a population of at most this many windows finishes a stage stump-parallel (lane = stump)
+constexpr uint32_t CV_TAIL_MAX = 64;        // a population of at most CvChainDev::tail_max <= this many windows evaluates a stage stump-parallel (lane = stump)
 constexpr uint32_t CV_TAIL_BLOCKS = 8;      // ... stages of up to 8 x 64 nodes
-constexpr uint32_t CV_TQ_CHUNK = 256;       // windows per chunk of cv_tree_chain_pass
+constexpr uint32_t CV_TQ_CHUNK = 256;       // windows per chunk of cv_tree_chain_pass at most (LDS: 24 bytes each; CvTreeArgs::chunk <= this)
 
 constexpr int CV_WAVES_PER_BLOCK = 4;
 constexpr int VJ_MAX_STAGES_DEV = 64;  // == VJ_MAX_STAGES
@@ -473,6 +485,7 @@ struct CvTreeArgs {
     CvChainDev chains;
     void* fail_scratch;          // CV_TQ_CHUNK x 24 bytes per wave
     uint32_t total_waves;
+    uint32_t chunk;              // windows a wave draws at a time (64 .. CV_TQ_CHUNK)
 };
 int launch_cv_tree_walk(const CvTreeArgs& a, int n_blocks, void* stream);
 int launch_cv_tree_chain_pass(const CvTreeArgs& a, int n_blocks, void* stream);

@@ -354,6 +354,30 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
                 pl->units.push_back(UnitDev{slot, f, std::min<uint32_t>(UNIT_WINDOWS, sd.nwin - f), 0});
         }
     }
+    // Band-major order: the units of a frame sorted by the image band their top row lies in, then by scale — the waves of an
+    // XCD (which take a contiguous run of the (frame, unit) list) then gather from ONE band of the sum image across all scales
+    // instead of sweeping the frame once per scale — and, for the queue pass, groups of consecutive units of one (band, scale).
+    if (e->q_band_px > 0 && !pl->units.empty()) {
+        auto band_of = [&](const UnitDev& u) {
+            const ScaleDev& sd = pl->scales[u.scale];
+            const uint32_t iy0 = u.bw != 0u ? (u.first >> 16) : u.first / std::max(1u, sd.nx);
+            return (uint32_t)std::lrint((double)((float)iy0 * sd.step)) / (uint32_t)e->q_band_px;
+        };
+        std::vector<std::pair<uint32_t, UnitDev>> keyed;
+        keyed.reserve(pl->units.size());
+        for (const UnitDev& u : pl->units) keyed.push_back({band_of(u), u});
+        std::stable_sort(keyed.begin(), keyed.end(), [](const auto& a, const auto& b) {
+            return std::make_tuple(a.first, a.second.scale) < std::make_tuple(b.first, b.second.scale);   // (stable: blocks stay row-major inside)
+        });
+        const uint32_t G = (uint32_t)std::max(1, e->q_group_units);
+        for (size_t i = 0; i < keyed.size(); ++i) {
+            pl->units[i] = keyed[i].second;
+            if (pl->unit_groups.empty() || pl->unit_groups.back().bw != keyed[i].first || pl->unit_groups.back().scale != keyed[i].second.scale ||
+                pl->unit_groups.back().count >= G)
+                pl->unit_groups.push_back(UnitDev{keyed[i].second.scale, (uint32_t)i, 0u, keyed[i].first});
+            ++pl->unit_groups.back().count;
+        }
+    }
     pl->pass_bounds = default_pass_bounds(c, pl->prog, e->split_override, e->pass_cut_nodes);
     if (pl->general) {   // positions in StageDev::order: [linear prefix | the rest]
         if (pl->general_prefix) pl->pass_bounds = {0u, pl->general_prefix, pl->n_order};
@@ -523,6 +547,10 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
     if (!pos_tab.empty()) {
         if ((rc = pl->d_pos_tab.ensure(pos_tab.size() * sizeof(uint32_t)))) return rc;
         HIP_TRY(hipMemcpy(pl->d_pos_tab.p, pos_tab.data(), pos_tab.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    }
+    if (!pl->unit_groups.empty()) {
+        if ((rc = pl->d_unit_groups.ensure(pl->unit_groups.size() * sizeof(UnitDev)))) return rc;
+        HIP_TRY(hipMemcpy(pl->d_unit_groups.p, pl->unit_groups.data(), pl->unit_groups.size() * sizeof(UnitDev), hipMemcpyHostToDevice));
     }
     if ((rc = pl->d_sp_blocks.ensure(std::max<size_t>(sp_blocks.size(), 1) * sizeof(SpBlock)))) return rc;
     if (!sp_blocks.empty())
@@ -1222,6 +1250,14 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
         };
         auto pass_is_last = [&](size_t ps) { return pl->seg_last.empty() ? ps + 1 == n_pass : pl->seg_last[ps] != 0; };
         const bool general_kernel = pl->general && pl->seg_last.empty();   // run_stages_general finishes the tree
+        // Band-major queue pass: a batch of a linear cascade whose gather chain is grid pass + ONE queue pass that only the grid
+        // pass feeds (the tiles run the whole cascade themselves)
+        const bool banded = e->q_band_px > 0 && !pl->unit_groups.empty() && !pl->general && n_pass == 2 && nf >= e->q_band_min_frames &&
+                            e->tile_min_lanes == 0 && (uint32_t)e->tile_end >= pl->pass_bounds[1] && !(e->global_blocks && pl->n_block_units > 0 && pl->sp_pad != 0);
+        if (banded) {
+            if ((rc = e->d_run_table.ensure((size_t)nf * pl->units.size() * 8u))) return rc;
+            ca.run_table = (uint32_t*)e->d_run_table.p;
+        }
         auto queue_args = [&](size_t ps, int set = 0) {
             CascadeArgs qa = ca;
             DevBuf* dq = set ? e->d_q2 : e->d_q;
@@ -1242,6 +1278,10 @@ static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_
             qa.wide_tail = (e->wide_tail < 0 ? nf <= 4 : e->wide_tail != 0) ? 1u : 0u;
             qa.q_out = last ? nullptr : (QEntry*)dq[ps + 1].p;
             qa.q_out_count = last ? nullptr : qc[ps + 1];
+            if (banded && ps == 1) {
+                qa.q_groups = (const UnitDev*)pl->d_unit_groups.p;
+                qa.n_q_groups = (uint32_t)pl->unit_groups.size();
+            }
             if (!pl->seg_fail.empty() && pl->seg_fail[ps] != 0) {   // stage tree: this segment's rejects continue
                 qa.q_fail = (QEntry*)dq[pl->seg_fail[ps]].p;
                 qa.q_fail_count = qc[pl->seg_fail[ps]];
@@ -1911,7 +1951,7 @@ void vj_env_destroy(vj_env* e) {
     drop_plans(e);
     for (DevBuf* b : {&e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_tilted, &e->d_out,
                       &e->d_skip_bits, &e->d_rois, &e->d_roi_units, &e->d_roi_det, &e->d_roi_tiles, &e->d_group, &e->d_cv_det, &e->d_cv_counts,
-                      &e->d_cv_accept, &e->d_cv_tq, &e->d_cv_fail_rows, &e->d_cv_fail_walk})
+                      &e->d_cv_accept, &e->d_cv_tq, &e->d_cv_fail_rows, &e->d_cv_fail_walk, &e->d_run_table})
         b->release();
     e->lane0.destroy();
     for (DevBuf& b : e->d_q) b.release();
@@ -2014,6 +2054,26 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "tree_split_queues") == 0) {
         e->tree_split_queues = atoi(value) != 0;
+        return VJ_OK;
+    }
+    if (strcmp(key, "q_band_px") == 0 || strcmp(key, "q_group_units") == 0) {   // band-major first-pass units and queue pass (0: off)
+        (strcmp(key, "q_band_px") == 0 ? e->q_band_px : e->q_group_units) = std::max(0, atoi(value));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "q_band_min_frames") == 0) {
+        e->q_band_min_frames = std::max(1, atoi(value));
+        return VJ_OK;
+    }
+    if (strcmp(key, "cv_tail_max") == 0) {   // (part of the plan: cached plans are dropped)
+        e->cv_tail_max = std::max(0, std::min(atoi(value), (int)CV_TAIL_MAX));
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
+        return VJ_OK;
+    }
+    if (strcmp(key, "cv_tree_chunk") == 0 || strcmp(key, "cv_tree_chain_blocks") == 0) {
+        (strcmp(key, "cv_tree_chunk") == 0 ? e->cv_tree_chunk : e->cv_tree_chain_blocks) = std::max(1, atoi(value));
         return VJ_OK;
     }
     if (strcmp(key, "cv_tree_chains") == 0) {   // OpenCV profile, stage trees made of chains: compacting chain sweeps (1) or the per-lane walk (0)

@@ -56,7 +56,9 @@ struct Plan {
     std::vector<ScaleDev> scales;            // accepted scales with nwin > 0
     std::vector<vj_scale_info> scales_info;  // same order as `scales`
     std::vector<StageDev> stages;
-    std::vector<UnitDev> units;              // first-pass units of one frame (global-gather scales)
+    std::vector<UnitDev> units;              // first-pass units of one frame (global-gather scales), band-major (q_band_px)
+    std::vector<UnitDev> unit_groups;        // runs of consecutive units of one (band, scale): what a wave of the band-major queue pass draws
+    DevBuf d_unit_groups;
     std::vector<UnitDev> tile_units;         // first-pass tiles of one frame, grouped by LDS class
     uint32_t class_first[TILE_CLASSES + 1] = {};  // tile_units range of each class
     uint32_t class_lds[TILE_CLASSES] = {};        // dynamic LDS bytes of each class launch
@@ -91,7 +93,7 @@ struct Plan {
     uint64_t last_used = 0;   // vj_env::plan_tick of the last call that used this plan (LRU eviction)
     float tile_split = 0.0f;  // the chain balance this plan was built for (vj_env::split_for)
     void release_device() {
-        for (DevBuf* b : {&d_table, &d_scales, &d_stages, &d_units, &d_tile_units, &d_sp_blocks, &d_skip_units, &d_skip_segs, &d_pos_tab}) b->release();
+        for (DevBuf* b : {&d_table, &d_scales, &d_stages, &d_units, &d_tile_units, &d_sp_blocks, &d_skip_units, &d_skip_segs, &d_pos_tab, &d_unit_groups}) b->release();
     }
 };
 
@@ -180,8 +182,8 @@ struct vj_env {
     // frame is bound by the latency of the gather chain's thin queue pass (measured, 1080p / frontalface_alt: 1 frame
     // 1.20 / 1.46 / 1.46 ms at split 0 / 0.5 / 1.25; 4 frames 3.50 / 3.61 / 3.96; 16 frames 12.51 / 12.25 / 12.36;
     // 64 frames — / 48.0 / 54.0), so small batches keep everything they can on the tiles
-    float tile_split = 1.5f;            // batches of >= 32 frames (four gather waves; 64 x 1080p: 46.70 / 46.24 / 45.57 / 45.16 / 45.55 / 46.72 ms for 0.75 / 1 / 1.25 / 1.5 / 1.75 / 2; 32: 23.39 / 23.16 / 22.80 / 22.62 / 22.78 / 23.38)
-    float tile_split_mid = 1.25f;       // 8 .. 31 frames (16 x 1080p: 11.81 / 11.67 / 11.47 / 11.52 / 11.86 for 0.75 ... 1.75; 8: 6.03 / 5.95 / 5.97 / 6.24); 5 .. 7 frames (three gather waves): at most 0.5
+    float tile_split = 2.0f;            // batches of >= 32 frames (round 4, band-major queue pass: 64 x 1080p 43.6 / 43.0 / 42.5 / 43.4 / 44.5 ms for 1.5 / 1.75 / 2 / 2.25 / 2.5; round 3: (four gather waves; 64 x 1080p: 46.70 / 46.24 / 45.57 / 45.16 / 45.55 / 46.72 ms for 0.75 / 1 / 1.25 / 1.5 / 1.75 / 2; 32: 23.39 / 23.16 / 22.80 / 22.62 / 22.78 / 23.38)
+    float tile_split_mid = 1.75f;       // 8 .. 31 frames (round 4, band-major queue pass: 16 x 1080p 11.53 / 11.36 / 11.13 / 11.01 / 10.89 / 10.90 ms for 0.75 ... 2.0; round 3: (16 x 1080p: 11.81 / 11.67 / 11.47 / 11.52 / 11.86 for 0.75 ... 1.75; 8: 6.03 / 5.95 / 5.97 / 6.24); 5 .. 7 frames (three gather waves): at most 0.5
     float tile_split_small = 0.0f;      // <= 4 frames
     float split_for(int n_frames) const {
         return n_frames <= 4 ? tile_split_small : n_frames < 8 ? std::min(tile_split_mid, 0.5f) : n_frames < 32 ? tile_split_mid : tile_split;
@@ -212,6 +214,7 @@ struct vj_env {
     vj::DevBuf d_q[vj::MAX_PASSES];   // d_q[p]: windows waiting to enter pass p (p >= 1)
     vj::DevBuf d_q2[vj::MAX_PASSES];  // stage trees: the tiles' own queue set (enqueue_cascade: split_sets)
     vj::DevBuf d_skip_bits;           // P2 skip modes: visited-window bitmaps of the frames in flight
+    vj::DevBuf d_run_table;           // band-major queue pass: where every first-pass unit's survivors sit in their sub-queue
     vj::DevBuf d_rois, d_roi_units, d_roi_det, d_roi_tiles;   // regions of interest on the device (vj_detect_chain)
     uint32_t roi_tile_cap = 0;
     int roi_tile_min_windows = 512;   // region pass: (region, scale) grids of at least this many windows run on LDS tiles (0: never)
@@ -282,7 +285,9 @@ struct vj_env {
     bool cv_tiles = true;         // OpenCV profile: small scales of stump cascades on LDS tiles (vj_cv_tile.hip)
     int cv_tile_ws_max = 512;     // ... windows a tile carries into its wave-split finish
     int cv_row_blocks = 3;        // ... workgroups per CU of cv_profile_pass while it runs next to the tiles (their LDS budget shrinks with it)
-    int cv_row_blocks_tree = 2, cv_tile_min_windows_tree = 512;   // ... the same two for stage trees (swept: profiles/r03_cv_sweeps.log)
+    int cv_row_blocks_tree = 2, cv_tile_min_windows_tree = 256;   // ... the same two for stage trees (swept: profiles/r03_cv_sweeps.log)
+    int cv_tail_max = 64;             // ... a population of at most this many windows evaluates a stage stump-parallel (<= 64)
+    int cv_tree_chunk = 64, cv_tree_chain_blocks = 2;   // ... windows per chunk and workgroups per CU of cv_tree_chain_pass
     bool cv_tree_chains = true;       // ... stage trees made of chains: compacting chain sweeps (0: the per-lane target-stage walk)
     int cv_tq_shift = 4;              // ... stage trees: the survivors' queue holds 1 / 2^shift of the tile windows (grows on overflow)
     int cv_tree_queue_cap = 0;        // ... stage trees: capacity of the prefix survivors' queue (0: a quarter of the tile windows)
@@ -291,6 +296,10 @@ struct vj_env {
     bool rois_on_device = true;   // vj_detect_rois: one region pass on the frames' integral images (0: one vj_detect per region size)
     int wide_tail = -1;           // queue passes: several windows in flight in the stump-parallel tail (-1: batches of <= 4 frames)
     int min_chunk = 32;           // queue passes: smallest chunk of windows a wave draws when there are fewer than 64 per wave
+    int q_band_px = 128;          // first-pass units of a frame are ordered by image band of this height (then scale), and the queue pass of a
+                                  // batch draws groups of units band-major (0: scale-major units, chunk-by-chunk queue pass)
+    int q_group_units = 4;        // ... units per group (their survivors fill a wave's 512-entry queue about once: 2-4 equal, 5 / 6 / 8 / 16 lose 0.5 / 1 / 2-3 / 3-7 ms of 42.5)
+    int q_band_min_frames = 8;    // ... batches of at least this many frames (a single frame keeps the thin-pass machinery)
     int q_slices = -1;            // queue passes: slices of a part handed out frame-major (-1: one per frame of the part's frame group)
     bool thin_pass_spread = true; // queue passes with fewer chunks than waves: only the first workgroups draw tickets
     int sp_tail_max = 48;         // global-gather sweeps switch to the stump-parallel tail when a wave holds at most this many windows (0: never)

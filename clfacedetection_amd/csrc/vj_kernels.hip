@@ -21,7 +21,32 @@
 #ifndef VJ_STAMPS
 #define VJ_STAMPS 0
 #endif
+// Experiment switch (tools/ab_build.sh): pin the scalar loads of the NEXT node record(s) at the top of a stump iteration,
+// ahead of the iteration's LDS gathers.  hipcc otherwise sinks them to the end of the iteration — LDS and scalar loads share
+// lgkmcnt, and an outstanding scalar load turns every counted LDS wait into lgkmcnt(0) — where their latency is exposed
+// (profiles/r04_notes.md #3).
+#ifndef VJ_SCHED_PREFETCH
+#define VJ_SCHED_PREFETCH 0
+#endif
+#define VJ_PIN_PREFETCH() do { } while (0)
 namespace vj {
+
+// The next node record, fetched through the scalar cache WITHOUT telling the compiler's wait-count pass: the load is issued
+// where it stands (hipcc sinks an ordinary load of `tab[j + 1]` to the end of the iteration, next to its first use, because a
+// scalar load in flight turns every counted LDS wait into lgkmcnt(0)), the iteration's LDS gathers keep their counted waits
+// (an extra operation in flight only makes a counted wait stricter), and rec_arrived() — an explicit lgkmcnt(0) that the
+// record's uses depend on — stands where the record is needed.
+__device__ __forceinline__ NodeRecDev rec_fetch(kptr<NodeRecDev> p) {
+    NodeRecDev r;
+    // (the address is wave-uniform by construction; where the compiler cannot prove it, it must still sit in SGPRs)
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint64_t u = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) |
+                       (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32;
+    asm volatile("s_load_dwordx16 %0, %1, 0x0" : "=&s"(r) : "s"(u));
+    return r;
+}
+__device__ __forceinline__ void rec_arrived(NodeRecDev& r) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r)); }
+__device__ __forceinline__ void rec_arrived(NodeRecDev& a, NodeRecDev& b) { asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)); }
 
 // Sum of a float over the 64 lanes, left in lane 63, with DPP adds only (no LDS crossbar traffic):
 // butterflies inside quads and rows of 16, then row_bcast15 / row_bcast31 across the rows.  The
@@ -149,6 +174,53 @@ __global__ __launch_bounds__(256) void band_scan(IntegralArgs a) {
     }
 }
 
+// The same prefix over the bands in TWO levels, for latency: one workgroup takes 64 columns, wave g the g-th group of BPG bands —
+// every lane loads its column's BPG band totals at once (one memory round trip instead of n_bands / 8 dependent ones: the
+// single-frame integral is latency-bound, 135 bands at 1080p), scans them in registers, and adds the totals of the groups
+// above from LDS.  Same arithmetic (integer adds), same outputs as band_scan.
+template <int BPG>
+__global__ __launch_bounds__(1024) void band_scan2(IntegralArgs a) {
+    __shared__ uint32_t tot_s[16][64];
+    __shared__ uint64_t tot_q[16][64];
+    const uint32_t lane = threadIdx.x & 63u, g = threadIdx.x >> 6;
+    const uint32_t x = blockIdx.x * 64u + lane, frame = blockIdx.y;
+    const bool in = x < a.band_pitch;
+    const uint32_t b0 = g * (uint32_t)BPG;
+    const size_t o = ((size_t)frame * a.n_bands + b0) * a.band_pitch + x;
+    uint32_t ts[BPG], tq[BPG];
+#pragma unroll
+    for (int k = 0; k < BPG; ++k) {
+        const bool have = in && b0 + (uint32_t)k < a.n_bands;
+        ts[k] = have ? a.band_sum[o + (size_t)k * a.band_pitch] : 0u;
+        tq[k] = have ? a.band_sq[o + (size_t)k * a.band_pitch] : 0u;
+    }
+    uint32_t s = 0;
+    uint64_t q = 0;
+#pragma unroll
+    for (int k = 0; k < BPG; ++k) {
+        s += ts[k];
+        q += tq[k];
+    }
+    tot_s[g][lane] = s;
+    tot_q[g][lane] = q;
+    __syncthreads();
+    s = 0;
+    q = 0;
+    for (uint32_t h = 0; h < g; ++h) {   // (uniform trip count per wave)
+        s += tot_s[h][lane];
+        q += tot_q[h][lane];
+    }
+#pragma unroll
+    for (int k = 0; k < BPG; ++k) {
+        if (in && b0 + (uint32_t)k < a.n_bands) {
+            a.band_sum[o + (size_t)k * a.band_pitch] = s;         // exclusive prefix, in place
+            a.band_sq_prefix[o + (size_t)k * a.band_pitch] = q;
+        }
+        s += ts[k];
+        q += tq[k];
+    }
+}
+
 // Inclusive prefix sums over the 64 lanes with DPP adds only (no LDS crossbar traffic): shifts by 1, 2, 4, 8 inside
 // the rows of 16, then row_bcast15 / row_bcast31 carry the row totals on.
 template <int CTRL, int ROW_MASK>
@@ -195,7 +267,7 @@ typedef uint64_t u64x2_unaligned __attribute__((ext_vector_type(2), aligned(8)))
 // to 66051 pixels (Q = uint32_t: one 32-bit DPP scan per row and image); wider images scan in 64 bits.  All integer
 // arithmetic: the sum wraps mod 2^32 like CV_32S whatever the order of the additions, the squared sum is exact.
 template <typename Q>
-__global__ __launch_bounds__(256) void band_rows(IntegralArgs a) {
+__device__ __forceinline__ void band_rows_body(const IntegralArgs& a) {
     const uint32_t lane = lane_id();
     const uint32_t band = blockIdx.x * 4u + (threadIdx.x >> 6);
     const uint32_t frame = blockIdx.y;
@@ -298,16 +370,38 @@ __global__ __launch_bounds__(256) void band_rows(IntegralArgs a) {
     }
 }
 
+// Two register budgets of the same body: the compiler's own choice (178-192 VGPRs, two waves per SIMD: the fastest for one
+// frame, which is latency-bound) and three waves per SIMD (168 VGPRs, 44-92 bytes of scratch per lane: 8-10 % faster on batches,
+// which are bound by stores in flight — 64 x 1080p 0.721 -> 0.664 ms, 256 x 720p 1.325 -> 1.199; four waves per SIMD spill 200-250 bytes
+// and lose it again: profiles/r04_notes.md #6).
+template <typename Q>
+__global__ __launch_bounds__(256) void band_rows(IntegralArgs a) { band_rows_body<Q>(a); }
+template <typename Q>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void band_rows_w3(IntegralArgs a) { band_rows_body<Q>(a); }
+
 int launch_integral(const IntegralArgs& a, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const uint32_t quads = a.band_pitch / 4u;
     dim3 g1((quads + 255u) / 256u, a.n_bands, a.n_frames);
     hipLaunchKernelGGL(band_colsum, g1, dim3(256), 0, stream, a);
-    dim3 g2((a.band_pitch + 255u) / 256u, a.n_frames, 1);
-    hipLaunchKernelGGL(band_scan, g2, dim3(256), 0, stream, a);
+    // prefix over the bands: two levels (16 groups per workgroup) while a group stays <= 32 bands (images up to 4096 rows)
+    const dim3 g2b((a.band_pitch + 63u) / 64u, a.n_frames, 1);
+    if (a.n_bands <= 16u * 8u) hipLaunchKernelGGL(band_scan2<8>, g2b, dim3(1024), 0, stream, a);
+    else if (a.n_bands <= 16u * 16u) hipLaunchKernelGGL(band_scan2<16>, g2b, dim3(1024), 0, stream, a);
+    else if (a.n_bands <= 16u * 32u) hipLaunchKernelGGL(band_scan2<32>, g2b, dim3(1024), 0, stream, a);
+    else {
+        dim3 g2((a.band_pitch + 255u) / 256u, a.n_frames, 1);
+        hipLaunchKernelGGL(band_scan, g2, dim3(256), 0, stream, a);
+    }
     dim3 g3((a.n_bands + 3u) / 4u, a.n_frames, 1);
-    if ((uint64_t)a.width * 65025ull < (1ull << 32)) hipLaunchKernelGGL(band_rows<uint32_t>, g3, dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL(band_rows<uint64_t>, g3, dim3(256), 0, stream, a);
+    const bool batch = (uint64_t)a.n_frames * a.n_bands >= 2048u;   // enough bands in flight to fill the chip several times
+    if ((uint64_t)a.width * 65025ull < (1ull << 32)) {
+        if (batch) hipLaunchKernelGGL(band_rows_w3<uint32_t>, g3, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(band_rows<uint32_t>, g3, dim3(256), 0, stream, a);
+    } else {
+        if (batch) hipLaunchKernelGGL(band_rows_w3<uint64_t>, g3, dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL(band_rows<uint64_t>, g3, dim3(256), 0, stream, a);
+    }
     return (int)hipGetLastError();
 }
 
@@ -457,12 +551,19 @@ __device__ __forceinline__ float stage_sum_stumps(const Img& img, kptr<NodeRecDe
         for (; j + 1u < n_nodes; j += 2u) {
             // fetch the next pair while this one is evaluated (scalar loads are long)
             const uint32_t ja = j + 2u < n_nodes ? j + 2u : j, jb = j + 3u < n_nodes ? j + 3u : j + 1u;
+#if VJ_SCHED_PREFETCH
+            NodeRecDev na = rec_fetch(tab + ja), nb = rec_fetch(tab + jb);
+#else
             const NodeRecDev na = tab[ja], nb = tab[jb];
+#endif
             float sa, sb;
             node_rect_sum_pair(img, ra, rb, off, sa, sb);
             // alpha[rect_sum >= norm_threshold]: alpha[0] = left_val, alpha[1] = right_val
             stage_sum += (sa >= __uint_as_float(ra[11]) * var) ? __uint_as_float(ra[13]) : __uint_as_float(ra[12]);
             stage_sum += (sb >= __uint_as_float(rb[11]) * var) ? __uint_as_float(rb[13]) : __uint_as_float(rb[12]);
+#if VJ_SCHED_PREFETCH
+            rec_arrived(na, nb);
+#endif
             ra = na;
             rb = nb;
         }
@@ -487,7 +588,11 @@ __device__ __forceinline__ void stage_sum_stumps_multi(const Img& img, kptr<Node
     for (int c = 0; c < NC; ++c) stage_sum[c] = 0.0f;
     NodeRecDev r = tab[0];
     for (uint32_t j = 0; j < n_nodes; ++j) {
+#if VJ_SCHED_PREFETCH
+        NodeRecDev rn = rec_fetch(tab + (j + 1 < n_nodes ? j + 1 : j));
+#else
         const NodeRecDev rn = tab[j + 1 < n_nodes ? j + 1 : j];
+#endif
         const float thr = __uint_as_float(r[11]), left = __uint_as_float(r[12]), right = __uint_as_float(r[13]);
         // node_rect_sum, rectangle-major across the chunks so that all 8*NC gathers of the first two
         // rectangles are in flight together (the uniform third-rectangle branch would otherwise cut the
@@ -533,6 +638,9 @@ __device__ __forceinline__ void stage_sum_stumps_multi(const Img& img, kptr<Node
         }
 #pragma unroll
         for (int c = 0; c < NC; ++c) stage_sum[c] += (rect_sum[c] >= thr * var[c]) ? right : left;
+#if VJ_SCHED_PREFETCH
+        rec_arrived(rn);
+#endif
         r = rn;
     }
 }
@@ -849,7 +957,7 @@ __device__ __forceinline__ uint32_t frame_part(const CascadeArgs& a, uint32_t fr
 template <bool TREES, bool LAST, bool COUNT, int NW = 1>
 __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t img_r, QEntry* q, uint32_t n,
                                                   uint32_t scale_slot, uint32_t table_first, uint32_t q_base,
-                                                  uint32_t lane, uint32_t begin, uint32_t part) {
+                                                  uint32_t lane, uint32_t begin, uint32_t part, uint32_t run_idx = 0xffffffffu) {
     kptr<NodeRecDev> table = as_k(reinterpret_cast<const NodeRecDev*>(a.table)) + table_first;
     const GlobalImg img{img_r};
     FailSink fail;
@@ -858,7 +966,10 @@ __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t i
         fail.count = a.q_fail_count + scale_slot * Q_PARTS + part;
     }
     n = sweep_stages<TREES, COUNT, false, NW>(a, img, table, q, n, lane, begin, a.stage_end, fail);
-    if (n == 0u) return;
+    if (n == 0u) {
+        if (!LAST && run_idx != 0xffffffffu && lane == 0) *reinterpret_cast<uint2*>(a.run_table + 2u * (size_t)run_idx) = make_uint2(0u, 0u);
+        return;
+    }
     if (LAST) {
         uint32_t g = 0;
         if (lane == 0) g = atomicAdd(a.det_count, n);
@@ -872,6 +983,8 @@ __device__ __forceinline__ void run_stages_linear(const CascadeArgs& a, rsrc_t i
         g = __builtin_amdgcn_readfirstlane(g);
         const size_t base = (size_t)q_base + (size_t)part * as_k(a.scales)[scale_slot].q_cap;
         for (uint32_t i = lane; i < n; i += 64u) a.q_out[base + g + i] = q[i];
+        // where this unit's survivors sit: the band-major queue pass finds them by unit
+        if (run_idx != 0xffffffffu && lane == 0) *reinterpret_cast<uint2*>(a.run_table + 2u * (size_t)run_idx) = make_uint2(g, n);
     }
 }
 
@@ -1020,7 +1133,54 @@ __global__ __launch_bounds__(GATHER_WAVES_MAX * 64) void cascade_pass(CascadeArg
                                                  scales[slot].table_first, lane);
             else
                 run_stages_linear<TREES, LAST, COUNT>(a, img, q, n_q, slot, scales[slot].table_first,
-                                                      scales[slot].q_base, lane, a.stage_begin, frame_part(a, frame));
+                                                      scales[slot].q_base, lane, a.stage_begin, frame_part(a, frame),
+                                                      a.run_table != nullptr ? u : 0xffffffffu);
+            __builtin_amdgcn_wave_barrier();
+        }
+    } else if (!GENERAL && a.q_groups != nullptr) {
+        // Band-major queue pass (see CascadeArgs::run_table).  The (frame, group) list is cut by frame group — the parts of the
+        // sub-queues — with one ticket counter each; an XCD's waves start on "their" part and steal from the others.
+        kptr<UnitDev> groups = as_k(a.q_groups);
+        kptr<uint32_t> runs = as_k(a.run_table);
+        const uint32_t nG = a.n_q_groups;
+        uint32_t part = a.xcd_affinity != 0u ? (blockIdx.x & (Q_PARTS - 1u)) : 0u;
+        for (uint32_t tries = 0; tries < Q_PARTS;) {
+            // frames of this part: frame_part(f) == part  <=>  f in [ceil(part * n / 8), ceil((part + 1) * n / 8))
+            // (fewer frames than parts: part = frame)
+            const uint32_t f_lo = a.n_frames >= Q_PARTS ? (uint32_t)(((unsigned long long)part * a.n_frames + Q_PARTS - 1u) / Q_PARTS) : min(part, a.n_frames);
+            const uint32_t f_hi = a.n_frames >= Q_PARTS ? (uint32_t)(((unsigned long long)(part + 1u) * a.n_frames + Q_PARTS - 1u) / Q_PARTS)
+                                                        : min(part + 1u, a.n_frames);
+            const uint32_t n_items = (f_hi - f_lo) * nG;
+            uint32_t t = n_items;
+            if (n_items != 0u) {
+                if (lane == 0) t = atomicAdd(a.q_ticket + part, 1u);
+                t = __builtin_amdgcn_readfirstlane(t);
+            }
+            if (t >= n_items) {   // this part is used up: steal from the next one
+                part = (part + 1u) & (Q_PARTS - 1u);
+                ++tries;
+                continue;
+            }
+            const uint32_t frame = f_lo + t / nG, gi = t - (t / nG) * nG;
+            const uint32_t slot = groups[gi].scale, u0 = groups[gi].first, nu = groups[gi].count;
+            const uint32_t q_base = scales[slot].q_base;
+            const size_t base = (size_t)q_base + (size_t)part * scales[slot].q_cap;
+            uint32_t n_q = 0;
+            for (uint32_t k = 0; k < nu; ++k) {
+                const size_t ri = ((size_t)frame * a.n_units + u0 + k) * 2u;
+                const uint32_t g = runs[ri], n = runs[ri + 1u];
+                if (n == 0u) continue;
+                if (n_q + n > (uint32_t)UNIT_WINDOWS) {   // the wave's queue is full: sweep what it holds first
+                    __builtin_amdgcn_wave_barrier();
+                    run_stages_linear<TREES, LAST, COUNT, NW>(a, img, q, n_q, slot, scales[slot].table_first, q_base, lane, a.stage_begin, part);
+                    __builtin_amdgcn_wave_barrier();
+                    n_q = 0;
+                }
+                for (uint32_t i = lane; i < n; i += 64u) q[n_q + i] = a.q_in[base + g + i];
+                n_q += n;
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (n_q != 0u) run_stages_linear<TREES, LAST, COUNT, NW>(a, img, q, n_q, slot, scales[slot].table_first, q_base, lane, a.stage_begin, part);
             __builtin_amdgcn_wave_barrier();
         }
     } else {
@@ -1295,11 +1455,13 @@ __global__ __launch_bounds__(256) void roi_plan_units(RoiArgs r, CascadeArgs a) 
         if (r.tiles != nullptr && scales[slot].tile_rw != 0u && scales[slot].tile_class == 0u && nwin >= r.tile_min_windows && nx < 65536 &&
             ny < 65536) {
             // a grid worth staging: tiles of the scale's tile shape inside the region (cascade_tile_roi_pass)
-            const uint32_t tw = scales[slot].tile_tw, th = scales[slot].tile_th;
-            const uint32_t tx = ((uint32_t)nx + tw - 1u) / tw, ty = ((uint32_t)ny + th - 1u) / th;
+            const uint32_t tw_s = scales[slot].tile_tw, th_s = scales[slot].tile_th;
+            const uint32_t tx = ((uint32_t)nx + tw_s - 1u) / tw_s, ty = ((uint32_t)ny + th_s - 1u) / th_s;
+            // equal parts: the tiles of a region have the same shape (and the last one is not a sliver)
+            const uint32_t tw = ((uint32_t)nx + tx - 1u) / tx, th = ((uint32_t)ny + ty - 1u) / ty;
             const uint32_t base = atomicAdd(r.n_tiles, tx * ty);
             for (uint32_t j = 0; j < tx * ty && base + j < r.max_tiles; ++j)
-                r.tiles[base + j] = RoiTile{roi, slot, (j % tx) * tw | ((j / tx) * th) << 16, (uint32_t)nx | (uint32_t)ny << 16};
+                r.tiles[base + j] = RoiTile{roi, slot, (j % tx) * tw | ((j / tx) * th) << 16, (uint32_t)nx | (uint32_t)ny << 16, tw | th << 16};
             continue;
         }
         const uint32_t nun = (nwin + UNIT_WINDOWS - 1u) / UNIT_WINDOWS;
@@ -1811,7 +1973,11 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
                         NodeRecDev ra = tab[w0], rb = tab[min(w0 + 1u, j1 - 1u)];
                         for (; k + 1u < m; k += 2u) {
                             // the next pair's records travel while this pair is evaluated
+#if VJ_SCHED_PREFETCH
+                            NodeRecDev na = rec_fetch(tab + min(w0 + k + 2u, j1 - 1u)), nb = rec_fetch(tab + min(w0 + k + 3u, j1 - 1u));
+#else
                             const NodeRecDev na = tab[min(w0 + k + 2u, j1 - 1u)], nb = tab[min(w0 + k + 3u, j1 - 1u)];
+#endif
                             float sa, sb;
                             node_rect_sum_pair(img, ra, rb, e.off, sa, sb);
                             const bool pa = sa >= __uint_as_float(ra[11]) * e.var, pb = sb >= __uint_as_float(rb[11]) * e.var;
@@ -1819,6 +1985,9 @@ __device__ __forceinline__ uint32_t tile_wave_split(const CascadeArgs& a, const 
                             psum += pb ? __uint_as_float(rb[13]) : __uint_as_float(rb[12]);
                             bw |= (pa ? 1u : 0u) << k;
                             bw |= (pb ? 2u : 0u) << k;
+#if VJ_SCHED_PREFETCH
+                            rec_arrived(na, nb);
+#endif
                             ra = na;
                             rb = nb;
                         }
@@ -1986,8 +2155,21 @@ __device__ __forceinline__ void tile_pass_body(const CascadeArgs& a, const RoiAr
         }
         const float step = scales[slot].step;
         const uint32_t pos_base = scales[slot].pos_base;
-        const uint32_t tw = scales[slot].tile_tw, th = scales[slot].tile_th;
-        const uint32_t pitch = STAGED ? scales[slot].tile_pitch : 0u, rows = STAGED ? scales[slot].tile_rows : 0u;
+        uint32_t tw = scales[slot].tile_tw, th = scales[slot].tile_th;
+        const uint32_t pitch = STAGED ? scales[slot].tile_pitch : 0u;
+        uint32_t rows = STAGED ? scales[slot].tile_rows : 0u, cols = pitch;   // rows / columns of the image tile that are staged
+        if constexpr (ROI) {
+            // a region's tile may be smaller than the scale's: fewer rows and columns to stage.  The scale's tile spans
+            // ceil((t - 1) * step) + margin pixels (host, double); floor(...) + 2 of the smaller shape against floor(...) of the
+            // full one never trims a pixel the smaller tile reads (one spare row / column at most)
+            const uint32_t tw_s = tw, th_s = th;
+            tw = as_k(r_->tiles)[u].twh & 0xffffu;
+            th = as_k(r_->tiles)[u].twh >> 16;
+            const uint32_t full_y = (uint32_t)((float)(th_s - 1u) * step), need_y = (uint32_t)((float)(th - 1u) * step) + 2u;
+            const uint32_t full_x = (uint32_t)((float)(tw_s - 1u) * step), need_x = (uint32_t)((float)(tw - 1u) * step) + 2u;
+            if (need_y < full_y) rows -= full_y - need_y;
+            if (need_x < full_x) cols -= full_x - need_x;
+        }
         const uint32_t frame_bytes = frame * frame_bytes4;   // < 2^32, checked on the host
         const size_t frame_off = (size_t)frame * a.frame_elems;
         const rsrc_t sum_f = make_rsrc(a.sum + frame_off, frame_bytes4);
@@ -2008,17 +2190,17 @@ __device__ __forceinline__ void tile_pass_body(const CascadeArgs& a, const RoiAr
             if (half == 0u && x4 != 0u) {
                 // 16 bytes per lane, 1 KiB per instruction: a quarter of the texture-address work of the dword form
                 // (which the global-gather chain on the same CU is competing for)
-                for (uint32_t c0 = 0; c0 < pitch; c0 += 256u) {
+                for (uint32_t c0 = 0; c0 < cols; c0 += 256u) {
                     const uint32_t soff = __builtin_amdgcn_readfirstlane(g_row + c0 * 4u);
-                    if (c0 + lane * 4u < pitch)
+                    if (c0 + lane * 4u < cols)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             sum_f, (__attribute__((address_space(3))) uint32_t*)(lds_img + rr * pitch + c0), 16,
                             lane * 16u, soff, 0, 0);
                 }
             } else if (half == 0u) {
-                for (uint32_t c0 = 0; c0 < pitch; c0 += 64u) {
+                for (uint32_t c0 = 0; c0 < cols; c0 += 64u) {
                     const uint32_t soff = __builtin_amdgcn_readfirstlane(g_row + c0 * 4u);   // keep it scalar
-                    if (c0 + lane < pitch)
+                    if (c0 + lane < cols)
                         __builtin_amdgcn_raw_ptr_buffer_load_lds(
                             sum_f, (__attribute__((address_space(3))) uint32_t*)(lds_img + rr * pitch + c0), 4,
                             lane * 4u, soff, 0, 0);
@@ -2027,7 +2209,7 @@ __device__ __forceinline__ void tile_pass_body(const CascadeArgs& a, const RoiAr
                 // de-interleave while staging: plane 0 takes image columns 0, 2, 4, ..., plane 1 the odd ones
                 // (LDS destinations stay lane-contiguous, the sources are 8 bytes apart)
                 for (uint32_t plane = 0; plane < 2u; ++plane) {
-                    const uint32_t n_cols = plane == 0u ? half : pitch - half;
+                    const uint32_t n_cols = min(plane == 0u ? half : pitch - half, (cols + 1u) / 2u + 1u);
                     for (uint32_t c0 = 0; c0 < n_cols; c0 += 64u) {
                         const uint32_t soff = __builtin_amdgcn_readfirstlane(g_row + (c0 * 2u + plane) * 4u);
                         if (c0 + lane < n_cols)

@@ -179,11 +179,16 @@ int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
  *                      global_blocks
  *   tile finish        tile_finish, tile_sp_begin, tile_sp_max, tile_ws_min, tile_ws_max
  *   chain balance      tile_split ("small,mid,large" or one value: static), auto_balance (1 / 0 / "reset": feedback on the
- *                      first calls of a batch workload)
- *   global-gather      grid_block_w, gather_pairs, sp_tail_max, wide_tail, min_chunk, thin_pass_spread, q_slices, xcd_affinity
+ *                      first calls of a batch workload, keyed by cascade content, frame size, parameters and batch-size class),
+ *                      balance_export / balance_import (value: a file path; the found balances as text, for another environment
+ *                      or process — import AFTER setting auto_balance, which clears the table), balance_exact (tests)
+ *   global-gather      grid_block_w, gather_waves, gather_pairs, sp_tail_max, wide_tail, min_chunk, thin_pass_spread, q_slices,
+ *                      xcd_affinity, q_band_px, q_group_units, q_band_min_frames (band-major first-pass units and queue pass)
  *   stage trees        general_prefix, tile_segments, seg_cut2, tree_split_queues
- *   regions / chain    rois_on_device, group_max
- *   OpenCV profile     cv_tiles, cv_row_blocks, cv_tile_min_windows, cv_tile_min_windows0, cv_tile_ws_max
+ *   regions / chain    rois_on_device, roi_tiles, group_max
+ *   OpenCV profile     cv_tiles, cv_row_blocks, cv_tile_min_windows, cv_tile_min_windows0, cv_tile_ws_max, cv_row_blocks_tree,
+ *                      cv_tile_min_windows_tree, cv_tree_chains, cv_tree_chunk, cv_tree_chain_blocks, cv_tail_max,
+ *                      cv_tree_queue_cap (tests)
  *   housekeeping       plan_cache_max
  * Unknown keys return VJ_ERR_ARG.                                               */
 int  vj_env_configure(vj_env* e, const char* key, const char* value);

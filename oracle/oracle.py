@@ -249,6 +249,8 @@ class Oracle:
         L.oc_detect.restype = C.c_int
         L.oc_xorshift_noise.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
         L.oc_xorshift_noise.restype = None
+        L.oc_xorshift_words.argtypes = [C.c_uint32, C.c_void_p, C.c_size_t]
+        L.oc_xorshift_words.restype = None
         L.oc_u64_to_f32.argtypes = [C.c_uint64]
         L.oc_u64_to_f32.restype = C.c_float
         L.oc_detect_opencvlike.argtypes = [C.POINTER(_OcCascade), C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
@@ -392,6 +394,11 @@ class Oracle:
         img = np.zeros((h, w), np.uint8)
         self.lib.oc_xorshift_noise(seed, img.ctypes.data, img.size)
         return img
+
+    def xorshift_words(self, seed: int, n: int) -> np.ndarray:
+        w = np.zeros(n, np.uint32)
+        self.lib.oc_xorshift_words(seed, w.ctypes.data, n)
+        return w
 
     def u64_to_f32(self, v: int) -> np.float32:
         return np.float32(self.lib.oc_u64_to_f32(v))

@@ -481,6 +481,17 @@ void oc_xorshift_noise(uint32_t seed, uint8_t* dst, size_t n) {
     }
 }
 
+/* The generator's 32-bit words themselves (the survey's `smooth` kind derives its noise in [-8, 8] from them). */
+void oc_xorshift_words(uint32_t seed, uint32_t* dst, size_t n) {
+    uint32_t s = seed ? seed : 1u;
+    for (size_t i = 0; i < n; ++i) {
+        s ^= s << 13;
+        s ^= s >> 17;
+        s ^= s << 5;
+        dst[i] = s;
+    }
+}
+
 /* u64 -> f32 conversion probe, for known-answer tests of the device conversion. */
 float oc_u64_to_f32(uint64_t v) { return (float)v; }
 

@@ -104,6 +104,41 @@ def test_device_resident_frames(env, cascades):
     assert np.array_equal(rd.rects, rh.rects) and rd.stage_entered == rh.stage_entered
 
 
+def test_band_major_queue_pass_equals_the_chunked_one(env, oracle, cascades):
+    """The band-major queue pass (first-pass units ordered by image band, the queue pass drawing groups of units through the run
+    table: vj_kernels.hip, CascadeArgs::run_table) against the chunk-by-chunk one and the oracle: rectangles, per-stage
+    counts, and per-launch counters; band heights / group sizes that leave one unit per group or one group per scale; frame
+    counts that do not divide by the eight queue parts; a batch below the switch-over keeps the chunked pass."""
+    c, a = cascades("frontalface_alt")
+    p = default_params(flags=VJ_FLAG_COUNTERS)
+    try:
+        for n_frames, (h, w) in ((11, (300, 420)), (8, (480, 640)), (3, (270, 500))):
+            frames = synth.batch(n_frames, h, w, seed0=333, kinds=("noise", "faces", "blocks"))
+            env.configure("q_band_px", 0)
+            base = env.detect(c, frames, p)
+            want = []
+            for f in range(n_frames):
+                ro, _ = oracle.detect(a, frames[f])
+                want += [(f,) + t[1:] for t in as_list(ro, True)]
+            assert as_list(base.rects, True) == want
+            for band, group, min_frames in ((128, 8, 1), (32, 1, 1), (4096, 64, 1), (64, 3, 1), (128, 8, 8)):
+                env.configure("q_band_px", band)
+                env.configure("q_group_units", group)
+                env.configure("q_band_min_frames", min_frames)
+                for tile_split in ("0", "1.5", "99"):      # nothing / the default share / every tile scale on the gather chain
+                    env.configure("tile_split", tile_split)
+                    r = env.detect(c, frames, p)
+                    assert np.array_equal(r.rects, base.rects) and r.stage_entered == base.stage_entered, (n_frames, band, group, tile_split)
+                    assert [sum(l["stage_entered"][s] for l in r.launches) for s in range(len(r.stage_entered))] == r.stage_entered
+                    r2 = env.detect(c, frames)          # the timed (uncounted) kernel variants
+                    assert np.array_equal(r2.rects, base.rects)
+    finally:
+        env.configure("q_band_px", 128)
+        env.configure("q_group_units", 8)
+        env.configure("q_band_min_frames", 8)
+        env.configure("tile_split", "0,1.75,2")
+
+
 def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
     c, _ = cascades("frontalface_alt")
     frames = synth.batch(2, 480, 640, seed0=70)
@@ -144,7 +179,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("concurrent", 1)
         env.configure("tile_lds_reserve_kb", 16)
         env.configure("global_blocks", 0)
-        env.configure("tile_split", "0,1.25,1.5")
+        env.configure("tile_split", "0,1.75,2")
         env.configure("grid_block_w", 32)
         # LDS-tile path off / small / large tiles / shallow / deep: the tile and the
         # global-gather paths agree bit for bit
@@ -168,7 +203,7 @@ def test_pass_split_and_occupancy_do_not_change_results(env, cascades):
         env.configure("concurrent", 1)
         env.configure("tile_lds_reserve_kb", 16)
         env.configure("global_blocks", 0)
-        env.configure("tile_split", "0,1.25,1.5")
+        env.configure("tile_split", "0,1.75,2")
         env.configure("grid_block_w", 32)
         env.configure("pass_split", "")
         env.configure("blocks_per_cu", 8)
@@ -511,7 +546,7 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
     assert len(set(splits[-6:])) == 1 and all(0.0 <= s <= 3.0 for s in splits)
     ro, _ = oracle.detect(a, frames[5])
     assert as_list(first.rects[first.rects["frame"] == 5]) == as_list(ro)
-    env.configure("tile_split", "0,1.25,1.5")             # static values: the feedback is off
+    env.configure("tile_split", "0,1.75,2")             # static values: the feedback is off
     try:
         assert {env.detect(c, frames).tile_split for _ in range(7)} == {1.25}      # (12 frames: the value for 8 .. 31)
         assert np.array_equal(env.detect(c, frames).rects, first.rects)
@@ -534,7 +569,7 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
             seen.append(r.tile_split)
         assert len(set(seen[-6:])) == 1 and len(set(seen)) >= 3, seen
     finally:
-        env.configure("tile_split", "0,1.25,1.5")
+        env.configure("tile_split", "0,1.75,2")
         env.configure("auto_balance", "reset")
     # vj_detect_chain searches the balance of its first cascade the same way: same two results in every call of the search
     eye, _ = cascades("eye")
