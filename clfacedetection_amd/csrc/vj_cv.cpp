@@ -138,10 +138,14 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
     }
     // (a stage tree's row kernel evaluates the whole tree at every grid position and is far slower per window than the tiles'
     // prefix: trees send every scale they can to tiles and leave the row kernel two workgroups per CU)
-    pl->row_blocks = is_tree ? e->cv_row_blocks_tree : e->cv_row_blocks;
+    // (linear cascades, profiles/r04_notes.md #5b: stumps 2 workgroups x tiles of >= 2048 windows — 64 x 1080p frontalface_alt 66.6 ms against 80.5
+    // at 3 x 1536, frontalface_default 51.4 / 57.1, 256 x 720p 112.7 / 136.9 —, two-node trees the other way round: frontalface_alt2 99.3 / 77.5)
+    const int lin_blocks = e->cv_row_blocks > 0 ? e->cv_row_blocks : trees ? 3 : 2;
+    const int lin_min_windows = e->cv_tile_min_windows > 0 ? e->cv_tile_min_windows : trees ? 1536 : 2048;
+    pl->row_blocks = is_tree ? e->cv_row_blocks_tree : lin_blocks;
     // a call of <= 4 frames is bound by latency, not by the balance of two saturated chains: one row-kernel workgroup per CU
     // and every scale that has a tile of 512 windows on tiles (one 1080p frame: 2.4 -> 2.0 ms)
-    int min_windows = is_tree ? e->cv_tile_min_windows_tree : e->cv_tile_min_windows, min_windows0 = e->cv_tile_min_windows0;
+    int min_windows = is_tree ? e->cv_tile_min_windows_tree : lin_min_windows, min_windows0 = e->cv_tile_min_windows0;
     if (small_batch && !is_tree) {
         pl->row_blocks = 1;
         min_windows = std::min(min_windows, 512);
@@ -509,6 +513,8 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             a.det_count = (uint32_t*)((unsigned long long*)d_counts.p + 2 * VJ_MAX_STAGES);
             a.det_cap = det_cap;
             a.stage_entered = (unsigned long long*)d_counts.p;
+            a.tail_max = (uint32_t)std::max(0, std::min(e->cv_tail_max, (int)CV_TAIL_MAX));
+            a.pairs = e->cv_pairs ? 1u : 0u;
             if (is_tree && pl->chains.n != 0u && !count && e->cv_tree_chains) {   // the rows kernel sweeps the chains too (cv_chain_sweep): a fail list per wave
                 a.chains = pl->chains;
                 const size_t waves = (size_t)std::max(1, e->n_cu * 4) * CV_WAVES_PER_BLOCK;

@@ -127,6 +127,7 @@ __device__ __forceinline__ double cv_stage_sum_mode(rsrc_t img, rsrc_t timg, kpt
 // One stump stage on the lane's window, two stumps per step with all of their gathers in flight (a thin sweep pays a memory
 // round trip per step); the leaf values are added in stump order.  Stage trees never take the two_rects f64 branch
 // (StageDev::cv_f64 is 0 for them): int * float products widened to double (:783-788).
+template <bool F64 = false>
 __device__ __forceinline__ double cv_stage_sum_pairs(rsrc_t img, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off, double vnf) {
     double stage_sum = 0.0;
     uint32_t j = 0;
@@ -137,12 +138,18 @@ __device__ __forceinline__ double cv_stage_sum_pairs(rsrc_t img, kptr<NodeRecDev
             const NodeRecDev na = tab[ja], nb = tab[jb];   // the next pair travels meanwhile
             const int32_t a0 = cv_calc_sum(img, off, ra[0], ra[3], ra[6]), a1 = cv_calc_sum(img, off, ra[1], ra[4], ra[7]);
             const int32_t b0 = cv_calc_sum(img, off, rb[0], rb[3], rb[6]), b1 = cv_calc_sum(img, off, rb[1], rb[4], rb[7]);
-            double sa = (double)((float)a0 * __uint_as_float(ra[9]));
-            sa += (double)((float)a1 * __uint_as_float(ra[10]));
-            double sb = (double)((float)b0 * __uint_as_float(rb[9]));
-            sb += (double)((float)b1 * __uint_as_float(rb[10]));
+            double sa, sb;
+            if (F64) {   // a two_rects stump stage (tempcv.cpp:872-888): f64 products, rect1 + rect0
+                sa = (double)a1 * (double)__uint_as_float(ra[10]) + (double)a0 * (double)__uint_as_float(ra[9]);
+                sb = (double)b1 * (double)__uint_as_float(rb[10]) + (double)b0 * (double)__uint_as_float(rb[9]);
+            } else {
+                sa = (double)((float)a0 * __uint_as_float(ra[9]));
+                sa += (double)((float)a1 * __uint_as_float(ra[10]));
+                sb = (double)((float)b0 * __uint_as_float(rb[9]));
+                sb += (double)((float)b1 * __uint_as_float(rb[10]));
+            }
             const float wa2 = __uint_as_float(ra[11]), wb2 = __uint_as_float(rb[11]);
-            if (wa2 != 0.0f || wb2 != 0.0f) {   // uniform (an absent third rectangle has lt = da = db = 0: four reads of the origin)
+            if (!F64 && (wa2 != 0.0f || wb2 != 0.0f)) {   // uniform (an absent third rectangle has lt = da = db = 0: four reads of the origin)
                 const int32_t a2 = cv_calc_sum(img, off, ra[2], ra[5], ra[8]), b2 = cv_calc_sum(img, off, rb[2], rb[5], rb[8]);
                 if (wa2 != 0.0f) sa += (double)((float)a2 * wa2);
                 if (wb2 != 0.0f) sb += (double)((float)b2 * wb2);
@@ -155,7 +162,7 @@ __device__ __forceinline__ double cv_stage_sum_pairs(rsrc_t img, kptr<NodeRecDev
     }
     if (j < n_nodes) {
         const NodeRecDev r = tab[j];
-        const double s = cv_node_sum<false>(img, img, r, off);
+        const double s = cv_node_sum<F64>(img, img, r, off);
         stage_sum += (double)(s < (double)__uint_as_float(r[12]) * vnf ? __uint_as_float(r[13]) : __uint_as_float(r[14]));
     }
     return stage_sum;
@@ -166,7 +173,7 @@ __device__ __forceinline__ double cv_stage_sum_pairs(rsrc_t img, kptr<NodeRecDev
 // per lane), a __ballot gives the block's verdict bits; then lane w adds window w's leaf values IN STUMP ORDER (the leaf values
 // come through the scalar cache).  Returns the pass mask (bit w: window w passes).  Upright features only (the caller checks).
 // `masks`: n x CV_TAIL_BLOCKS words of LDS scratch.
-template <typename E>
+template <bool F64 = false, typename E>
 __device__ __forceinline__ unsigned long long cv_tail_stage(rsrc_t img, const uint32_t* recs_g, kptr<NodeRecDev> tab, uint32_t n_nodes, double thr_stage,
                                                             const E* q, uint32_t n, unsigned long long* masks, uint32_t lane) {
     const uint32_t n_blocks = (n_nodes + 63u) >> 6;
@@ -184,11 +191,17 @@ __device__ __forceinline__ unsigned long long cv_tail_stage(rsrc_t img, const ui
             auto rect = [&](uint32_t lt, uint32_t da, uint32_t db) {
                 return (int32_t)(ld_u32(img, lt, uo) - ld_u32(img, lt + da, uo) - ld_u32(img, lt + db, uo) + ld_u32(img, lt + da + db, uo));
             };
-            const int32_t c0 = rect(lt0, da0, db0), c1 = rect(lt1, da1, db1), c2 = rect(lt2, da2, db2);
-            double sum = (double)((float)c0 * w0);
-            sum += (double)((float)c1 * w1);
-            const double with2 = sum + (double)((float)c2 * w2);
-            sum = w2 != 0.0f ? with2 : sum;
+            const int32_t c0 = rect(lt0, da0, db0), c1 = rect(lt1, da1, db1);
+            double sum;
+            if (F64) {   // two_rects stump stage: f64 products, rect1 + rect0 (tempcv.cpp:872-888)
+                sum = (double)c1 * (double)w1 + (double)c0 * (double)w0;
+            } else {
+                const int32_t c2 = rect(lt2, da2, db2);
+                sum = (double)((float)c0 * w0);
+                sum += (double)((float)c1 * w1);
+                const double with2 = sum + (double)((float)c2 * w2);
+                sum = w2 != 0.0f ? with2 : sum;
+            }
             const unsigned long long m = __ballot(active && !(sum < (double)thr_node * e.vnf));   // bit: alpha[1] (right)
             if (lane == 0) masks[w * CV_TAIL_BLOCKS + b] = m;
         }
@@ -312,12 +325,27 @@ __device__ __forceinline__ void cv_flush(const CvArgs& a, rsrc_t img, rsrc_t tim
         const uint32_t n_nodes = stages[s].n_nodes, f64 = stages[s].cv_f64;
         const double thr = (double)stages[s].threshold;
         uint32_t m = 0;
+        const bool upright = !TREES && a.tilted == nullptr;   // (the pair / stump-parallel forms read the upright sum image only)
+        if (upright && n <= a.tail_max && n_nodes >= 16u && n_nodes <= CV_TAIL_BLOCKS * 64u) {
+            // a thin population: the stage stump-parallel (lane = stump), verdict bits replayed in stump order (cv_tail_stage)
+            const uint32_t* recs_g = reinterpret_cast<const uint32_t*>((uintptr_t)(table + stages[s].first_node));
+            unsigned long long* masks = reinterpret_cast<unsigned long long*>(q + CV_TAIL_MAX);
+            const unsigned long long pm = f64 != 0u ? cv_tail_stage<true>(img, recs_g, tab, n_nodes, thr, q, n, masks, lane)
+                                                    : cv_tail_stage<false>(img, recs_g, tab, n_nodes, thr, q, n, masks, lane);
+            const CvQEntry e = q[lane < n ? lane : 0u];
+            __builtin_amdgcn_wave_barrier();
+            if ((pm >> lane) & 1ull) q[mbcnt(pm)] = e;
+            n = (uint32_t)__popcll(pm);
+            __builtin_amdgcn_wave_barrier();
+            continue;
+        }
         for (uint32_t base = 0; base < n; base += 64u) {
             const uint32_t i = base + lane;
             const bool act = i < n;
             const CvQEntry e = q[act ? i : 0u];
             bool pass = false;
-            if (act) pass = cv_stage_sum_mode<TREES>(img, timg, tab, n_nodes, e.off, e.vnf, f64) >= thr;
+            if (act && upright && a.pairs != 0u) pass = (f64 != 0u ? cv_stage_sum_pairs<true>(img, tab, n_nodes, e.off, e.vnf) : cv_stage_sum_pairs<false>(img, tab, n_nodes, e.off, e.vnf)) >= thr;
+            else if (act) pass = cv_stage_sum_mode<TREES>(img, timg, tab, n_nodes, e.off, e.vnf, f64) >= thr;
             const unsigned long long mask = __ballot(pass);
             __builtin_amdgcn_wave_barrier();
             if (pass) q[m + mbcnt(mask)] = e;

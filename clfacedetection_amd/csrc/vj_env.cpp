@@ -2066,6 +2066,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         e->q_band_min_frames = std::max(1, atoi(value));
         return VJ_OK;
     }
+    if (strcmp(key, "cv_pairs") == 0) {
+        e->cv_pairs = atoi(value) != 0;
+        return VJ_OK;
+    }
     if (strcmp(key, "cv_tail_max") == 0) {   // (part of the plan: cached plans are dropped)
         e->cv_tail_max = std::max(0, std::min(atoi(value), (int)CV_TAIL_MAX));
         HIP_TRY(hipStreamSynchronize(e->stream));
@@ -2099,11 +2103,11 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         const int v = atoi(value);
         if (strcmp(key, "cv_tiles") == 0) e->cv_tiles = v != 0;
         else if (strcmp(key, "cv_tile_ws_max") == 0) e->cv_tile_ws_max = std::max(0, std::min(v, (int)CVT_WS_MAX));
-        else if (strcmp(key, "cv_row_blocks") == 0) e->cv_row_blocks = std::max(1, std::min(v, 4));
+        else if (strcmp(key, "cv_row_blocks") == 0) e->cv_row_blocks = v < 0 ? -1 : std::max(1, std::min(v, 4));
         else if (strcmp(key, "cv_tile_min_windows0") == 0) e->cv_tile_min_windows0 = std::max(64, v);
         else if (strcmp(key, "cv_row_blocks_tree") == 0) e->cv_row_blocks_tree = std::max(1, std::min(v, 4));
         else if (strcmp(key, "cv_tile_min_windows_tree") == 0) e->cv_tile_min_windows_tree = std::max(64, v);
-        else e->cv_tile_min_windows = std::max(64, v);
+        else e->cv_tile_min_windows = v < 0 ? -1 : std::max(64, v);
         HIP_TRY(hipStreamSynchronize(e->stream));
         for (auto& kv : e->cv_plans) kv.second->release_device();
         e->cv_plans.clear();

@@ -284,15 +284,17 @@ struct vj_env {
     bool tree_split_queues = true; // stage trees: the grid pass's survivors go down the tree while the tiles still run
     bool cv_tiles = true;         // OpenCV profile: small scales of stump cascades on LDS tiles (vj_cv_tile.hip)
     int cv_tile_ws_max = 512;     // ... windows a tile carries into its wave-split finish
-    int cv_row_blocks = 3;        // ... workgroups per CU of cv_profile_pass while it runs next to the tiles (their LDS budget shrinks with it)
+    int cv_row_blocks = -1;       // ... workgroups per CU of cv_profile_pass while it runs next to the tiles (their LDS budget shrinks with it);
+                                  // -1: 2 for stump cascades (round 4: the row kernel's pair / stump-parallel forms need fewer waves), 3 for multi-node trees
     int cv_row_blocks_tree = 2, cv_tile_min_windows_tree = 256;   // ... the same two for stage trees (swept: profiles/r03_cv_sweeps.log)
+    bool cv_pairs = false;            // ... linear cascades' row kernel: two stumps per step in the sweeps of its queue
     int cv_tail_max = 64;             // ... a population of at most this many windows evaluates a stage stump-parallel (<= 64)
     int cv_tree_chunk = 64, cv_tree_chain_blocks = 2;   // ... windows per chunk and workgroups per CU of cv_tree_chain_pass
     bool cv_tree_chains = true;       // ... stage trees made of chains: compacting chain sweeps (0: the per-lane target-stage walk)
     int cv_tq_shift = 4;              // ... stage trees: the survivors' queue holds 1 / 2^shift of the tile windows (grows on overflow)
     int cv_tree_queue_cap = 0;        // ... stage trees: capacity of the prefix survivors' queue (0: a quarter of the tile windows)
     int cv_tile_min_windows0 = 2048;   // ... the same for the class with two tile workgroups per CU
-    int cv_tile_min_windows = 1536;   // ... a scale goes to tiles when a tile of at least this many windows fits the LDS
+    int cv_tile_min_windows = -1;     // ... a scale goes to tiles when a tile of at least this many windows fits the LDS (-1: 2048 for stump cascades, 1536 for trees)
     bool rois_on_device = true;   // vj_detect_rois: one region pass on the frames' integral images (0: one vj_detect per region size)
     int wide_tail = -1;           // queue passes: several windows in flight in the stump-parallel tail (-1: batches of <= 4 frames)
     int min_chunk = 32;           // queue passes: smallest chunk of windows a wave draws when there are fewer than 64 per wave

@@ -48,7 +48,7 @@ while time.time() - t0 < budget:
     kind = ["noise", "smooth", "blocks", "faces"][int(rng.integers(0, 4))]
     if kind == "faces" and min(h, w) < 130:
         kind = "noise"
-    nb = int(rng.integers(1, 5))
+    nb = int(rng.integers(1, 5)) if rng.random() < 0.8 else int(rng.integers(8, 24))      # (batches of >= 8: band-major queue pass, balance classes)
     img = frame(kind, n, h, w)
     batch = [img] * nb if nb > 1 else img
     op = int(rng.integers(0, 8))

@@ -529,6 +529,46 @@ def test_reserve_then_detect_other_sizes(oracle, cascades):
         clodReleaseEnvironment(env2)
 
 
+def test_balance_is_keyed_by_batch_size_class_and_travels(env, cascades, tmp_path):
+    """The feedback's table names a workload by the cascade's CONTENT, the frame size, the parameters and the batch-size CLASS
+    (8-15, 16-31, ...): another size of the same class runs the found split without a search of its own, another class searches
+    for itself, and an exported table lets a second environment start on the found split (results never depend on any of it)."""
+    from clfacedetection_amd import Environment, VjError
+    c, _ = cascades("frontalface_default")
+    frames = synth.batch(20, 360, 640, seed0=300)
+    env.configure("auto_balance", "reset")
+    env.configure("auto_balance", "1")
+    try:
+        want12 = env.detect(c, frames[:12])
+        r = want12
+        for _ in range(60):
+            if r.balance_state == 2:
+                break
+            r = env.detect(c, frames[:12])
+            assert np.array_equal(r.rects, want12.rects)
+        assert r.balance_state == 2
+        s12 = env.detect(c, frames[:12]).tile_split       # (the call that ended the search still ran its last candidate)
+        r9 = env.detect(c, frames[:9])                    # 9 frames: the class of 12
+        assert r9.balance_state == 2 and r9.tile_split == s12
+        r20 = env.detect(c, frames)                       # 20 frames: the next class starts its own search
+        assert r20.balance_state == 1 and r20.balance_calls <= 1
+        path = str(tmp_path / "balance.txt")
+        env.configure("balance_export", path)
+        lines = [l.split() for l in open(path) if l.startswith("vjbal1")]
+        assert len(lines) >= 2 and any(int(l[12]) == 8 and float(l[13]) == s12 and int(l[15]) == 3 for l in lines)
+        e2 = Environment(0)
+        try:
+            e2.configure("balance_import", path)
+            r2 = e2.detect(c, frames[:12])                # (a second load of the same cascade would hash the same too)
+            assert r2.balance_state == 2 and r2.tile_split == s12 and np.array_equal(r2.rects, want12.rects)
+            with pytest.raises(VjError):
+                e2.configure("balance_import", str(tmp_path / "missing.txt"))
+        finally:
+            e2.close()
+    finally:
+        env.configure("auto_balance", "reset")
+
+
 def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
     """vj_detect finds the chain balance of a batch workload (Plan::tile_split) by a short hill climb on the measured
     cascade time of its first calls, then freezes it: every call of the search returns the same rectangles (the split only
@@ -544,11 +584,12 @@ def test_chain_balance_feedback_does_not_change_results(env, oracle, cascades):
         assert np.array_equal(r.rects, first.rects)
         splits.append(r.tile_split)
     assert len(set(splits[-6:])) == 1 and all(0.0 <= s <= 3.0 for s in splits)
+    assert r.balance_state == 2 and 0 < r.balance_calls <= 45      # the search reports itself: finished, within its budget of measured calls
     ro, _ = oracle.detect(a, frames[5])
     assert as_list(first.rects[first.rects["frame"] == 5]) == as_list(ro)
     env.configure("tile_split", "0,1.75,2")             # static values: the feedback is off
     try:
-        assert {env.detect(c, frames).tile_split for _ in range(7)} == {1.25}      # (12 frames: the value for 8 .. 31)
+        assert {env.detect(c, frames).tile_split for _ in range(7)} == {1.75}      # (12 frames: the value for 8 .. 31)
         assert np.array_equal(env.detect(c, frames).rects, first.rects)
     finally:
         env.configure("auto_balance", "reset")

@@ -4,6 +4,7 @@
      python tools/configs.py config5 [calls]      256 x 720p, frontalface_alt2 -> eye inside the grouped faces, on the device
      python tools/configs.py config5raw [calls]   ... inside every raw candidate
      python tools/configs.py cv [calls]           64 x 1080p through the OpenCV arithmetic profile (vj_detect_opencv)
+     python tools/configs.py cvtree [calls]       ... with frontalface_alt_tree (stage tree: prefix on tiles, chain sweeps)
    key=value arguments go to vj_env_configure first.  Prints wall ms per call (median) and the per-launch HIP-event times."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -31,6 +32,9 @@ elif what in ("config5", "config5raw"):
     run = lambda i: env.detect_chain(face, eye, df, p1)[0]
 elif what == "cv":
     c, df = Cascade.load("frontalface_alt"), dev(synth.batch(64, 1080, 1920, seed0=1))
+    run = lambda i: env.detect_opencv(c, df)
+elif what == "cvtree":
+    c, df = Cascade.load("frontalface_alt_tree"), dev(synth.batch(64, 1080, 1920, seed0=1))
     run = lambda i: env.detect_opencv(c, df)
 else:
     sys.exit(__doc__)

@@ -12,7 +12,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from bench import kernel_source_hash
 
 src = sys.argv[1] if len(sys.argv) > 1 else "gpurun_out/prof"
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 os.makedirs("profiles", exist_ok=True)
 
 def per_kernel(d, counters):
@@ -27,7 +27,7 @@ def per_kernel(d, counters):
 
 for f in glob.glob(f"{src}/kt/*/*kernel_stats.csv"):
     shutil.copy(f, f"profiles/{tag}_kernel_stats.csv")
-for cfg in ("config2", "config4", "config5", "cv"):      # the other configs' kernel-trace summaries (tools/configs.py under rocprofv3)
+for cfg in ("config2", "config4", "config5", "cv", "cvtree"):      # the other configs' kernel-trace summaries (tools/configs.py under rocprofv3)
     for f in glob.glob(f"{src}/kt_{cfg}/*/*kernel_stats.csv"):
         shutil.copy(f, f"profiles/{tag}_{cfg}_kernel_stats.csv")
 fetch, write = per_kernel("fetch", {"FETCH_SIZE"}), per_kernel("write", {"WRITE_SIZE"})
