@@ -12,6 +12,7 @@
 // parity is against the oracle's restatement of the same lines (oc_detect_opencvlike): unpinned.
 #include "vj_env_internal.hpp"
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -339,6 +340,17 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
             pl->class_lds[cls] = lds;
         }
         pl->class_first[2] = (uint32_t)tiles.size();
+        // Band-major row order (cv_row_band_px != 0): the rows of ALL scales whose top lies in one band of the image, band after
+        // band.  The waves of an XCD walk one contiguous piece of the (frame, row) list together (cv_profile_pass), so what they
+        // gather from at one time is a band of one frame's integral image — within the XCD's 4 MB of L2 — instead of a whole
+        // scale's rows, i.e. the whole 8.3 MB image (rows are independent: the skip rule runs along a row).
+        if (e->cv_row_band_px > 0) {
+            const double band = (double)e->cv_row_band_px;
+            std::stable_sort(rows.begin(), rows.end(), [&](const UnitDev& x, const UnitDev& y) {
+                const uint32_t bx = (uint32_t)((double)x.first * scales[x.scale].ystep / band), by = (uint32_t)((double)y.first * scales[y.scale].ystep / band);
+                return bx != by ? bx < by : x.scale != y.scale ? x.scale < y.scale : x.first < y.first;
+            });
+        }
         for (const UnitDev& r : rows)
             if (scales[r.scale].tile_th == 0u) rows_rest.push_back(r);
     }
