@@ -140,8 +140,10 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
     // (a stage tree's row kernel evaluates the whole tree at every grid position and is far slower per window than the tiles'
     // prefix: trees send every scale they can to tiles and leave the row kernel two workgroups per CU)
     // (linear cascades, profiles/r04_notes.md #5b: stumps 2 workgroups x tiles of >= 2048 windows — 64 x 1080p frontalface_alt 66.6 ms against 80.5
-    // at 3 x 1536, frontalface_default 51.4 / 57.1, 256 x 720p 112.7 / 136.9 —, two-node trees the other way round: frontalface_alt2 99.3 / 77.5)
-    const int lin_blocks = e->cv_row_blocks > 0 ? e->cv_row_blocks : trees ? 3 : 2;
+    // at 3 x 1536, frontalface_default 51.4 / 57.1, 256 x 720p 112.7 / 136.9 —, multi-node trees the other way round: frontalface_alt2 99.3 / 77.5;
+    // two-node trees with both nodes fetched at once (CvArgs::tree2, #5d): 2 x 1536 69.9 ms against 80.9 at 3 x 1536)
+    const bool rows_tree2 = pl->tree2 && !is_tree && !has_tilted && e->cv_tree2;
+    const int lin_blocks = e->cv_row_blocks > 0 ? e->cv_row_blocks : trees && !rows_tree2 ? 3 : 2;
     const int lin_min_windows = e->cv_tile_min_windows > 0 ? e->cv_tile_min_windows : trees ? 1536 : 2048;
     pl->row_blocks = is_tree ? e->cv_row_blocks_tree : lin_blocks;
     // a call of <= 4 frames is bound by latency, not by the balance of two saturated chains: one row-kernel workgroup per CU
@@ -526,6 +528,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
             a.det_cap = det_cap;
             a.stage_entered = (unsigned long long*)d_counts.p;
             a.tail_max = (uint32_t)std::max(0, std::min(e->cv_tail_max, (int)CV_TAIL_MAX));
+            a.tree2 = pl->tree2 && !is_tree && !has_tilted && e->cv_tree2 ? 1u : 0u;
             a.pairs = e->cv_pairs ? 1u : 0u;
             if (is_tree && pl->chains.n != 0u && !count && e->cv_tree_chains) {   // the rows kernel sweeps the chains too (cv_chain_sweep): a fail list per wave
                 a.chains = pl->chains;

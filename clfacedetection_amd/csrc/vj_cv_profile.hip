@@ -107,12 +107,47 @@ __device__ __forceinline__ double cv_stage_sum(rsrc_t img, rsrc_t timg, kptr<Nod
     return stage_sum;
 }
 
+// Two-node trees (a root and its only node child — every tree of frontalface_alt2; upright features) with BOTH nodes' gathers
+// in flight: the walk above pays two memory round trips per tree — the child's under the lanes that go there — and a thin
+// sweep waits for each.  The tree's value is the walk's (tempcv.cpp:771-792: idx = sum < t ? left : right until idx <= 0):
+// the child's leaf where the root's side is a node, else the root's leaf; node sums int * float widened to double (:783-788).
+__device__ __forceinline__ double cv_stage_sum_tree2(rsrc_t img, kptr<NodeRecDev> tab, uint32_t n_trees, uint32_t off, double vnf) {
+    double stage_sum = 0.0;
+    NodeRecDev ra = tab[0], rb = tab[1];
+    for (uint32_t t = 0; t < n_trees; ++t) {
+        const uint32_t tn = t + 1u < n_trees ? t + 1u : t;
+        const NodeRecDev na = tab[2u * tn], nb = tab[2u * tn + 1u];   // the next tree travels meanwhile
+        const int32_t a0 = cv_calc_sum(img, off, ra[0], ra[3], ra[6]), a1 = cv_calc_sum(img, off, ra[1], ra[4], ra[7]);
+        const int32_t b0 = cv_calc_sum(img, off, rb[0], rb[3], rb[6]), b1 = cv_calc_sum(img, off, rb[1], rb[4], rb[7]);
+        double sa = (double)((float)a0 * __uint_as_float(ra[9]));
+        sa += (double)((float)a1 * __uint_as_float(ra[10]));
+        double sb = (double)((float)b0 * __uint_as_float(rb[9]));
+        sb += (double)((float)b1 * __uint_as_float(rb[10]));
+        const float wa2 = __uint_as_float(ra[11]), wb2 = __uint_as_float(rb[11]);
+        if (wa2 != 0.0f || wb2 != 0.0f) {   // uniform (an absent third rectangle has lt = da = db = 0: four reads of the origin)
+            const int32_t a2 = cv_calc_sum(img, off, ra[2], ra[5], ra[8]), b2 = cv_calc_sum(img, off, rb[2], rb[5], rb[8]);
+            if (wa2 != 0.0f) sa += (double)((float)a2 * wa2);
+            if (wb2 != 0.0f) sb += (double)((float)b2 * wb2);
+        }
+        const uint32_t flags = ra[15];
+        const bool left_a = sa < (double)__uint_as_float(ra[12]) * vnf, left_b = sb < (double)__uint_as_float(rb[12]) * vnf;
+        const bool to_child = left_a ? (flags & 1u) != 0u : (flags & 2u) != 0u;
+        const float leaf_a = left_a ? __uint_as_float(ra[13]) : __uint_as_float(ra[14]);
+        const float leaf_b = left_b ? __uint_as_float(rb[13]) : __uint_as_float(rb[14]);
+        stage_sum += (double)(to_child ? leaf_b : leaf_a);
+        ra = na;
+        rb = nb;
+    }
+    return stage_sum;
+}
+
 // Stage sum with the stage's arithmetic mode (StageDev::cv_f64, host-computed: two_rects && stump cascade && no
-// stage tree).
+// stage tree); `tree2`: CvArgs::tree2 (uniform).
 template <bool TREES>
 __device__ __forceinline__ double cv_stage_sum_mode(rsrc_t img, rsrc_t timg, kptr<NodeRecDev> tab, uint32_t n_nodes, uint32_t off,
-                                                    double vnf, uint32_t f64) {
+                                                    double vnf, uint32_t f64, uint32_t tree2 = 0u) {
     if (!TREES && f64 != 0u) return cv_stage_sum<false, true>(img, timg, tab, n_nodes, off, vnf);
+    if (TREES && tree2 != 0u) return cv_stage_sum_tree2(img, tab, n_nodes >> 1, off, vnf);
     return cv_stage_sum<TREES, false>(img, timg, tab, n_nodes, off, vnf);
 }
 
@@ -345,7 +380,7 @@ __device__ __forceinline__ void cv_flush(const CvArgs& a, rsrc_t img, rsrc_t tim
             const CvQEntry e = q[act ? i : 0u];
             bool pass = false;
             if (act && upright && a.pairs != 0u) pass = (f64 != 0u ? cv_stage_sum_pairs<true>(img, tab, n_nodes, e.off, e.vnf) : cv_stage_sum_pairs<false>(img, tab, n_nodes, e.off, e.vnf)) >= thr;
-            else if (act) pass = cv_stage_sum_mode<TREES>(img, timg, tab, n_nodes, e.off, e.vnf, f64) >= thr;
+            else if (act) pass = cv_stage_sum_mode<TREES>(img, timg, tab, n_nodes, e.off, e.vnf, f64, a.tree2) >= thr;
             const unsigned long long mask = __ballot(pass);
             __builtin_amdgcn_wave_barrier();
             if (pass) q[m + mbcnt(mask)] = e;
@@ -595,7 +630,7 @@ __global__ __launch_bounds__(CV_WAVES_PER_BLOCK * 64) void cv_profile_pass(CvArg
             }
             bool fail0 = false;
             if (eval)
-                fail0 = !(cv_stage_sum_mode<TREES>(img, timg, table + stages[0].first_node, stages[0].n_nodes, off, vnf, stages[0].cv_f64) >= thr0);
+                fail0 = !(cv_stage_sum_mode<TREES>(img, timg, table + stages[0].first_node, stages[0].n_nodes, off, vnf, stages[0].cv_f64, a.tree2) >= thr0);
             // which positions does the sequential walk visit?  parity of the reject run below each lane
             const unsigned long long F = __ballot(fail0);
             const bool visited = cv_visited(F, lane, n_valid, carry);

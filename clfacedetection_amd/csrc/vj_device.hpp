@@ -414,6 +414,7 @@ struct CvArgs {
     void* fail_scratch;          // ... CV_QCAP x 16 bytes per wave: where a chain's rejects wait for the next chain
     uint32_t tail_max;           // linear cascades: a wave's queue of at most this many windows evaluates a stage stump-parallel (<= CV_TAIL_MAX)
     uint32_t pairs;              // ... larger populations evaluate two stumps per step (all gathers in flight)
+    uint32_t tree2;              // every tree is a root + its only node child, upright (frontalface_alt2): both nodes' gathers in flight
 };
 
 int launch_cv_profile_pass(const CvArgs& a, bool trees, bool count, bool stage_tree, int n_blocks, void* stream);

@@ -2080,6 +2080,12 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         (strcmp(key, "cv_tree_chunk") == 0 ? e->cv_tree_chunk : e->cv_tree_chain_blocks) = std::max(1, atoi(value));
         return VJ_OK;
     }
+    if (strcmp(key, "cv_tree2") == 0) {   // (the default balance depends on it: cached plans are dropped)
+        e->cv_tree2 = atoi(value) != 0;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
+        return VJ_OK;
+    }
     if (strcmp(key, "cv_row_band_px") == 0) {   // OpenCV profile: row order of cv_profile_pass (part of the plan: cached plans are dropped)
         e->cv_row_band_px = std::max(0, atoi(value));
         HIP_TRY(hipStreamSynchronize(e->stream));

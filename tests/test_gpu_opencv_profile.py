@@ -245,8 +245,8 @@ def test_lds_tile_path_equals_the_row_kernel_and_the_oracle(env, oracle, cascade
             assert np.array_equal(env.detect_opencv(c, frames).rects, tiled.rects)
         finally:
             env.configure("cv_tree_queue_cap", 0)
-    defaults = {"cv_tile_ws_max": 512, "cv_tile_min_windows": -1, "cv_tile_min_windows0": 2048, "cv_row_blocks": -1, "concurrent": 1, "cv_row_band_px": 128}
-    for setting in ({"cv_tile_ws_max": 64}, {"cv_tile_ws_max": 0}, {"cv_tile_min_windows": 64, "cv_tile_min_windows0": 64}, {"cv_row_band_px": 0}, {"cv_row_band_px": 40},
+    defaults = {"cv_tile_ws_max": 512, "cv_tile_min_windows": -1, "cv_tile_min_windows0": 2048, "cv_row_blocks": -1, "concurrent": 1, "cv_row_band_px": 128, "cv_tree2": 1}
+    for setting in ({"cv_tile_ws_max": 64}, {"cv_tile_ws_max": 0}, {"cv_tile_min_windows": 64, "cv_tile_min_windows0": 64}, {"cv_row_band_px": 0}, {"cv_row_band_px": 40}, {"cv_tree2": 0},
                     {"cv_row_blocks": 1, "cv_tile_min_windows0": 512, "cv_tile_min_windows": 512}, {"concurrent": 0}):
         try:                         # finish thresholds, small tiles of both LDS classes, other occupancies, one stream: same result
             for key, val in setting.items():
