@@ -241,6 +241,7 @@ struct IntegralArgs {
     uint32_t* sum;              // [frames][frame_elems]
     uint64_t* sqsum;
     uint32_t frame_elems;
+    uint32_t rows_mode;         // band_rows: 0 one wave walks a band's chunks; 1 the chunks side by side (band_rows_par); 2 side by side unless the call is a batch
 };
 constexpr int BAND_ROWS = 8;
 

@@ -909,6 +909,7 @@ int enqueue_integral(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int s
     ia.sum = (uint32_t*)e->d_sum.p;
     ia.sqsum = (uint64_t*)e->d_sqsum.p;
     ia.frame_elems = frame_elems_for(W, H);
+    ia.rows_mode = (uint32_t)e->integral_rows_mode;
     // the slack rows after row H (and the alignment tail) must read as zero
     // (the kernels never write there, so once per buffer layout is enough)
     const size_t used = (size_t)(W + 1) * (size_t)(H + 1);
@@ -2301,6 +2302,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
             q = *endp ? endp + 1 : endp;
         }
         e->tile_repack_mask = m;
+        return VJ_OK;
+    }
+    if (strcmp(key, "integral_rows") == 0) {   // integral: see IntegralArgs::rows_mode
+        e->integral_rows_mode = std::max(0, std::min(atoi(value), 2));
         return VJ_OK;
     }
     if (strcmp(key, "blocks_per_cu") == 0) {

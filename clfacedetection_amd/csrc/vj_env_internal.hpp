@@ -260,6 +260,7 @@ struct vj_env {
                                   // (a stream of ROI sizes — eyes inside faces of any size — would otherwise grow
                                   // device tables without bound)
     // tunables (env vars, read once)
+    int integral_rows_mode = 2;      // band_rows: 0 one wave walks a band's chunks, 1 the chunks of a band side by side, 2 side by side except for batches
     int blocks_per_cu = 8;
     int tile_class_kb[vj::TILE_CLASSES] = {-2, -1, 0};  // image-tile LDS budget per class in KiB; -k = what lets k
                                                      // workgroups share a CU's 160 KiB; all 0 disables the tile path

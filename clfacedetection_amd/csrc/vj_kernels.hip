@@ -379,6 +379,161 @@ __global__ __launch_bounds__(256) void band_rows(IntegralArgs a) { band_rows_bod
 template <typename Q>
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void band_rows_w3(IntegralArgs a) { band_rows_body<Q>(a); }
 
+// The same rows with the CHUNKS of a band side by side instead of one after the other: a workgroup of up to eight waves takes one
+// band, wave w the 256 columns [x0 + 256 w, x0 + 256 (w + 1)) of every row of the band.  Each wave scans its chunk of the top
+// edge and of the eight rows on its own, the chunk totals (9 per wave, u32 + u64) meet in LDS, and a row's base is the totals
+// of the chunks to its left — so a band takes one chunk's latency instead of eight chunks' (one 1080p frame: 135 waves, each a
+// chain of 8 dependent chunks, were the whole launch), and a wave carries no per-row state from chunk to chunk (fewer registers:
+// more bands' stores in flight on a batch).  Images wider than 2048 pixels loop with a carry.  Same integer arithmetic, same
+// outputs as band_rows_body.
+template <typename Q>
+__global__ __launch_bounds__(512) void band_rows_par(IntegralArgs a) {
+    __shared__ uint32_t tot_s[2][BAND_ROWS + 1][8];
+    __shared__ uint64_t tot_q[2][BAND_ROWS + 1][8];
+    const uint32_t lane = lane_id();
+    const uint32_t w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), nw = blockDim.x >> 6;
+    const uint32_t band = blockIdx.x, frame = blockIdx.y;
+    const uint8_t* img = a.gray + (size_t)frame * a.gray_frame_bytes;
+    uint32_t* sum = a.sum + (size_t)frame * a.frame_elems;
+    uint64_t* sqs = a.sqsum + (size_t)frame * a.frame_elems;
+    const uint32_t ow = a.width + 1u;
+    const uint32_t y0 = band * BAND_ROWS;
+    const size_t bo = ((size_t)frame * a.n_bands + band) * a.band_pitch;
+    if (band == 0) {  // row 0 of both outputs is zero
+        for (uint32_t x = threadIdx.x; x < ow; x += blockDim.x) {
+            sum[x] = 0u;
+            sqs[x] = 0ull;
+        }
+    }
+    uint32_t carry_s[BAND_ROWS + 1];   // [0]: the band's top edge, [1 + r]: row r — totals left of the current group of chunks (uniform)
+    uint64_t carry_q[BAND_ROWS + 1];
+#pragma unroll
+    for (int r = 0; r <= BAND_ROWS; ++r) {
+        carry_s[r] = 0u;
+        carry_q[r] = 0ull;
+    }
+    uint32_t buf = 0;
+    for (uint32_t x0 = 0; x0 < a.width; x0 += 256u * nw, buf ^= 1u) {
+        const uint32_t x = x0 + w * 256u + lane * 4u;
+        const bool in = x < a.width;
+        uint32_t v[BAND_ROWS];
+#pragma unroll
+        for (int r = 0; r < BAND_ROWS; ++r)
+            v[r] = in && y0 + r < a.height ? load_gray4(img + (size_t)(y0 + r) * a.gray_stride, x, a.width, a.channels) : 0u;
+        uint32_t as[4] = {0, 0, 0, 0};
+        uint64_t aq[4] = {0, 0, 0, 0};
+        if (in) {  // column totals above the band
+            const uint4 t = *reinterpret_cast<const uint4*>(a.band_sum + bo + x);
+            as[0] = t.x; as[1] = as[0] + t.y; as[2] = as[1] + t.z; as[3] = as[2] + t.w;
+            const ulonglong2 u0 = *reinterpret_cast<const ulonglong2*>(a.band_sq_prefix + bo + x);
+            const ulonglong2 u1 = *reinterpret_cast<const ulonglong2*>(a.band_sq_prefix + bo + x + 2);
+            aq[0] = u0.x; aq[1] = aq[0] + u0.y; aq[2] = aq[1] + u1.x; aq[3] = aq[2] + u1.y;
+        }
+        // this chunk's own scans: exclusive prefixes per lane, totals to LDS
+        uint32_t ex_s[BAND_ROWS + 1], t_s[BAND_ROWS + 1];
+        uint64_t ex_top_q, t_q[BAND_ROWS + 1];
+        Q ex_q[BAND_ROWS];
+        {
+            const uint32_t is = wave_incl_scan(as[3]);
+            const uint64_t iq = wave_incl_scan(aq[3]);
+            ex_s[0] = is - as[3];
+            ex_top_q = iq - aq[3];
+            t_s[0] = wave_last(is);
+            t_q[0] = wave_last(iq);
+        }
+#pragma unroll
+        for (int r = 0; r < BAND_ROWS; ++r) {
+            uint32_t ls = 0;
+            Q lq = 0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                const uint32_t p = (v[r] >> (8 * c)) & 0xffu;
+                ls += p;
+                lq += (Q)(p * p);
+            }
+            const uint32_t is = wave_incl_scan(ls);
+            const Q iq = wave_incl_scan(lq);
+            ex_s[1 + r] = is - ls;
+            ex_q[r] = iq - lq;
+            t_s[1 + r] = wave_last(is);
+            t_q[1 + r] = (uint64_t)wave_last(iq);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r <= BAND_ROWS; ++r) {
+                tot_s[buf][r][w] = t_s[r];
+                tot_q[buf][r][w] = t_q[r];
+            }
+        }
+        __syncthreads();   // (one barrier per group: the totals are double-buffered)
+        // lane r adds up row r's totals: of the chunks to the left of this wave's, and of the whole group
+        uint32_t pre_s = 0, all_s = 0;
+        uint64_t pre_q = 0, all_q = 0;
+        if (lane <= (uint32_t)BAND_ROWS) {
+            for (uint32_t k = 0; k < nw; ++k) {
+                const uint32_t ts = tot_s[buf][lane][k];
+                const uint64_t tq = tot_q[buf][lane][k];
+                if (k < w) {
+                    pre_s += ts;
+                    pre_q += tq;
+                }
+                all_s += ts;
+                all_q += tq;
+            }
+        }
+        auto lane_u32 = [&](uint32_t val, int r) { return (uint32_t)__builtin_amdgcn_readlane((int)val, r); };
+        auto lane_u64 = [&](uint64_t val, int r) { return (uint64_t)lane_u32((uint32_t)val, r) | (uint64_t)lane_u32((uint32_t)(val >> 32), r) << 32; };
+        {
+            const uint32_t base_s = carry_s[0] + lane_u32(pre_s, 0) + ex_s[0];
+            const uint64_t base_q = carry_q[0] + lane_u64(pre_q, 0) + ex_top_q;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                as[c] += base_s;
+                aq[c] += base_q;
+            }
+            carry_s[0] += lane_u32(all_s, 0);
+            carry_q[0] += lane_u64(all_q, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < BAND_ROWS; ++r) {
+            const uint32_t y = y0 + r;
+            if (y < a.height) {  // uniform
+                const uint32_t base_s = carry_s[1 + r] + lane_u32(pre_s, 1 + r) + ex_s[1 + r];
+                const Q base_q = (Q)(carry_q[1 + r] + lane_u64(pre_q, 1 + r)) + ex_q[r];
+                uint32_t ls = 0;
+                Q lq = 0;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    const uint32_t p = (v[r] >> (8 * c)) & 0xffu;
+                    ls += p;
+                    lq += (Q)(p * p);
+                    as[c] += base_s + ls;
+                    aq[c] += (uint64_t)(Q)(base_q + lq);
+                }
+                const size_t ro = (size_t)(y + 1u) * ow;
+                if (x == 0u) {  // column 0 is zero
+                    sum[ro] = 0u;
+                    sqs[ro] = 0ull;
+                }
+                if (x + 4u <= a.width) {
+                    *reinterpret_cast<u32x4_unaligned*>(sum + ro + x + 1u) = u32x4_unaligned{as[0], as[1], as[2], as[3]};
+                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 1u) = u64x2_unaligned{aq[0], aq[1]};
+                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 3u) = u64x2_unaligned{aq[2], aq[3]};
+                } else {
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        if (x + c < a.width) {
+                            sum[ro + x + c + 1u] = as[c];
+                            sqs[ro + x + c + 1u] = aq[c];
+                        }
+                }
+                carry_s[1 + r] += lane_u32(all_s, 1 + r);
+                carry_q[1 + r] += lane_u64(all_q, 1 + r);
+            }
+        }
+    }
+}
+
 int launch_integral(const IntegralArgs& a, void* stream_) {
     hipStream_t stream = (hipStream_t)stream_;
     const uint32_t quads = a.band_pitch / 4u;
@@ -392,6 +547,16 @@ int launch_integral(const IntegralArgs& a, void* stream_) {
     else {
         dim3 g2((a.band_pitch + 255u) / 256u, a.n_frames, 1);
         hipLaunchKernelGGL(band_scan, g2, dim3(256), 0, stream, a);
+    }
+    if (a.rows_mode != 0u) {   // chunks of a band side by side (band_rows_par): 1 always, 2 for calls that are not batches
+        const bool batch_p = (uint64_t)a.n_frames * a.n_bands >= 2048u;
+        if (a.rows_mode == 1u || !batch_p) {
+            const uint32_t nw = min(8u, (a.width + 255u) / 256u);
+            dim3 gp(a.n_bands, a.n_frames, 1);
+            if ((uint64_t)a.width * 65025ull < (1ull << 32)) hipLaunchKernelGGL(band_rows_par<uint32_t>, gp, dim3(64u * nw), 0, stream, a);
+            else hipLaunchKernelGGL(band_rows_par<uint64_t>, gp, dim3(64u * nw), 0, stream, a);
+            return (int)hipGetLastError();
+        }
     }
     dim3 g3((a.n_bands + 3u) / 4u, a.n_frames, 1);
     const bool batch = (uint64_t)a.n_frames * a.n_bands >= 2048u;   // enough bands in flight to fill the chip several times

@@ -190,6 +190,7 @@ int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
  *                      cv_tile_min_windows_tree, cv_tree_chains, cv_tree_chunk, cv_tree_chain_blocks, cv_tail_max, cv_pairs,
  *                      cv_row_band_px, cv_tree2,
  *                      cv_tree_queue_cap (tests)
+ *   integral           integral_rows (0 one wave per band of rows, 1 a band's chunks side by side, 2 by call size)
  *   housekeeping       plan_cache_max
  * Unknown keys return VJ_ERR_ARG.                                               */
 int  vj_env_configure(vj_env* e, const char* key, const char* value);

@@ -34,7 +34,7 @@ CASC = {n: (Cascade.load(n), load_vjc(os.path.join(DATA_DIR, f"haarcascade_{n}.v
 TUNABLES = [("tile_split", ["0", "0.5", "1.3", "0,1.75,2"]), ("blocks_per_cu", ["1", "3", "8"]), ("gather_pairs", ["-1", "0", "2"]),
             ("sp_tail_max", ["0", "16", "48"]), ("thin_pass_spread", ["0", "1"]), ("tree_split_queues", ["0", "1"]), ("concurrent", ["0", "1"]),
             ("tile_classes_kb", ["-2,-1,0", "0,0,0", "24,40,60"]), ("grid_block_w", ["0", "32"]), ("max_subbatch", ["0", "2"]),
-            ("group_max", ["2048", "30"]), ("rois_on_device", ["1", "0"]), ("roi_tiles", ["512", "64", "0"]), ("wide_tail", ["-1", "0", "1"]), ("min_chunk", ["32", "64", "5"]),
+            ("group_max", ["2048", "30"]), ("rois_on_device", ["1", "0"]), ("roi_tiles", ["512", "64", "0"]), ("integral_rows", ["2", "0", "1"]), ("wide_tail", ["-1", "0", "1"]), ("min_chunk", ["32", "64", "5"]),
             ("q_slices", ["-1", "1", "5"]), ("gather_waves", ["-1", "3", "4"]), ("cv_tiles", ["1", "0"]), ("cv_tile_ws_max", ["512", "100", "0"]), ("cv_row_blocks", ["-1", "3", "1"]), ("cv_pairs", ["1", "0"]),
             ("cv_tile_min_windows", ["-1", "1536", "256", "64"]), ("cv_tile_min_windows0", ["2048", "512", "64"]), ("auto_balance", ["1", "0"]),
             # round 4: band-major queue pass (switched on for any batch size so that the soak's small batches reach it), chain sweeps of the
@@ -43,7 +43,7 @@ TUNABLES = [("tile_split", ["0", "0.5", "1.3", "0,1.75,2"]), ("blocks_per_cu", [
             ("cv_tree_chains", ["1", "0"]), ("cv_tree_chunk", ["64", "256", "100"]), ("cv_tail_max", ["64", "0", "20"]), ("cv_row_band_px", ["128", "0", "37"]), ("cv_tree2", ["1", "0"]),
             ("cv_tree_chain_blocks", ["2", "1"]), ("cv_tile_min_windows_tree", ["256", "64", "2048"]), ("balance_exact", ["0", "1"])]
 DEFAULTS = {"tile_split": "0,1.75,2", "blocks_per_cu": "8", "gather_pairs": "-1", "sp_tail_max": "48", "thin_pass_spread": "1", "tree_split_queues": "1",
-            "concurrent": "1", "tile_classes_kb": "-2,-1,0", "grid_block_w": "32", "max_subbatch": "0", "group_max": "2048", "rois_on_device": "1", "roi_tiles": "512", "wide_tail": "-1", "min_chunk": "32",
+            "concurrent": "1", "tile_classes_kb": "-2,-1,0", "grid_block_w": "32", "max_subbatch": "0", "group_max": "2048", "rois_on_device": "1", "roi_tiles": "512", "integral_rows": "2", "wide_tail": "-1", "min_chunk": "32",
             "q_slices": "-1", "gather_waves": "-1", "cv_tiles": "1", "cv_tile_ws_max": "512", "cv_row_blocks": "-1", "cv_tile_min_windows": "-1", "cv_tile_min_windows0": "2048",
             "auto_balance": "1", "q_band_px": "128", "q_group_units": "4", "q_band_min_frames": "8", "cv_tree_chains": "1", "cv_tree_chunk": "64",
             "cv_tail_max": "64", "cv_row_band_px": "128", "cv_tree2": "1", "cv_pairs": "1", "cv_tree_chain_blocks": "2", "cv_tile_min_windows_tree": "256", "balance_exact": "0"}

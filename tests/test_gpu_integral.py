@@ -10,6 +10,16 @@ from cases import INTEGRAL_CASES, make_frame, sha
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(__file__), "golden")
+ROWS_DEFAULT = 2
+
+
+@pytest.fixture(params=[0, 1, 2], autouse=True, ids=lambda m: f"rows{m}")
+def rows_mode(env, request):
+    """Every test of this file with each form of the row kernel: one wave walking a band's chunks (0), the chunks of a band side
+    by side in one workgroup (1), and the default's choice between them by call size (2)."""
+    env.configure("integral_rows", request.param)
+    yield request.param
+    env.configure("integral_rows", ROWS_DEFAULT)
 
 
 @pytest.mark.parametrize("g", json.load(open(os.path.join(G, "integral.json"))), ids=lambda d: d["id"])
