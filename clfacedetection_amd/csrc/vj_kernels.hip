@@ -260,13 +260,20 @@ __device__ __forceinline__ uint64_t wave_last(uint64_t v) {
 
 typedef uint32_t u32x4_unaligned __attribute__((ext_vector_type(4), aligned(4)));
 typedef uint64_t u64x2_unaligned __attribute__((ext_vector_type(2), aligned(8)));
+// NT: non-temporal stores — the batch variant's outputs (1.6 GB per 64 x 1080p) pass through the caches once and are read much
+// later; a call whose outputs fit the Infinity Cache keeps ordinary stores (profiles/r04_notes.md #6).
+template <bool NT, typename V>
+__device__ __forceinline__ void out_store(V* p, V v) {
+    if constexpr (NT) __builtin_nontemporal_store(v, p);
+    else *p = v;
+}
 
 // One wave per band of 8 rows, walking it in chunks of 256 columns (4 per lane).  The integral at (y, x) is the
 // integral at the band's top edge — a prefix along x of the column totals above the band, scanned once per chunk —
 // plus the prefixes along x of the band's rows down to y.  A row's prefix of squares stays below 2^32 for rows of up
 // to 66051 pixels (Q = uint32_t: one 32-bit DPP scan per row and image); wider images scan in 64 bits.  All integer
 // arithmetic: the sum wraps mod 2^32 like CV_32S whatever the order of the additions, the squared sum is exact.
-template <typename Q>
+template <typename Q, bool NT = false>
 __device__ __forceinline__ void band_rows_body(const IntegralArgs& a) {
     const uint32_t lane = lane_id();
     const uint32_t band = blockIdx.x * 4u + (threadIdx.x >> 6);
@@ -352,9 +359,9 @@ __device__ __forceinline__ void band_rows_body(const IntegralArgs& a) {
                 if (x + 4u <= a.width) {
                     // 16 (sum) and 32 (squared sum) contiguous bytes per lane: the wave writes
                     // contiguous 1 KiB / 2 KiB runs; rows are only 4-byte aligned (odd stride)
-                    *reinterpret_cast<u32x4_unaligned*>(sum + ro + x + 1u) = u32x4_unaligned{as[0], as[1], as[2], as[3]};
-                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 1u) = u64x2_unaligned{aq[0], aq[1]};
-                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 3u) = u64x2_unaligned{aq[2], aq[3]};
+                    out_store<NT>(reinterpret_cast<u32x4_unaligned*>(sum + ro + x + 1u), u32x4_unaligned{as[0], as[1], as[2], as[3]});
+                    out_store<NT>(reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 1u), u64x2_unaligned{aq[0], aq[1]});
+                    out_store<NT>(reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 3u), u64x2_unaligned{aq[2], aq[3]});
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
@@ -373,11 +380,12 @@ __device__ __forceinline__ void band_rows_body(const IntegralArgs& a) {
 // Two register budgets of the same body: the compiler's own choice (178-192 VGPRs, two waves per SIMD: the fastest for one
 // frame, which is latency-bound) and three waves per SIMD (168 VGPRs, 44-92 bytes of scratch per lane: 8-10 % faster on batches,
 // which are bound by stores in flight — 64 x 1080p 0.721 -> 0.664 ms, 256 x 720p 1.325 -> 1.199; four waves per SIMD spill 200-250 bytes
-// and lose it again: profiles/r04_notes.md #6).
+// and lose it again: profiles/r04_notes.md #6).  The batch variant also stores non-temporally (64 x 1080p -7 %, 256 x 720p -6 %; a single
+// 4096 x 4096 frame or 8 x 1080p, whose outputs the caches still hold when the cascade starts, +20-30 % with such stores: they keep the ordinary ones).
 template <typename Q>
 __global__ __launch_bounds__(256) void band_rows(IntegralArgs a) { band_rows_body<Q>(a); }
 template <typename Q>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void band_rows_w3(IntegralArgs a) { band_rows_body<Q>(a); }
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void band_rows_w3(IntegralArgs a) { band_rows_body<Q, true>(a); }
 
 // The same rows with the CHUNKS of a band side by side instead of one after the other: a workgroup of up to eight waves takes one
 // band, wave w the 256 columns [x0 + 256 w, x0 + 256 (w + 1)) of every row of the band.  Each wave scans its chunk of the top
@@ -516,9 +524,9 @@ __global__ __launch_bounds__(512) void band_rows_par(IntegralArgs a) {
                     sqs[ro] = 0ull;
                 }
                 if (x + 4u <= a.width) {
-                    *reinterpret_cast<u32x4_unaligned*>(sum + ro + x + 1u) = u32x4_unaligned{as[0], as[1], as[2], as[3]};
-                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 1u) = u64x2_unaligned{aq[0], aq[1]};
-                    *reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 3u) = u64x2_unaligned{aq[2], aq[3]};
+                    out_store<false>(reinterpret_cast<u32x4_unaligned*>(sum + ro + x + 1u), u32x4_unaligned{as[0], as[1], as[2], as[3]});
+                    out_store<false>(reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 1u), u64x2_unaligned{aq[0], aq[1]});
+                    out_store<false>(reinterpret_cast<u64x2_unaligned*>(sqs + ro + x + 3u), u64x2_unaligned{aq[2], aq[3]});
                 } else {
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
