@@ -32,7 +32,7 @@ struct DevBuf {
         if (p) (void)hipFree(p);
         p = nullptr;
         cap = 0;
-        // grow geometrically so alternating sizes do not reallocate every call
+        // (a buffer never shrinks: alternating sizes reallocate only when a request exceeds every earlier one)
         size_t want = std::max(bytes, (size_t)256);
         hipError_t e = hipMalloc(&p, want);
         if (e != hipSuccess) {
