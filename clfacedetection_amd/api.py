@@ -33,6 +33,7 @@ VJ_FLAG_SIGNED_MEAN = 1 << 1
 VJ_FLAG_SKIP_LIST = 1 << 2     # the CLOD_PER_STAGE_ITERATIONS CPU variant's skip over the flattened window list (clod.cpp:729-732)
 VJ_FLAG_SKIP_ROW = 1 << 3      # the plain CPU variant: round() positions, skip inside a row (clod.cpp:1409-1432)
 VJ_FLAG_GRID_F64 = 1 << 4      # + one of the two above: the same loop of the block variant, whose step is a double (clod.cpp:862)
+VJ_FLAG_TILTED_AS_UPRIGHT = 1 << 5   # clod profile: <tilted>1 rectangles count as upright ones, as in the reference (clod.cpp:448-492); else refused
 
 # clod_flags of the reference (clod.h:17-19).  They select among the reference's CPU
 # evaluators; the HIP path has one evaluator, so they are accepted and ignored.
@@ -639,7 +640,10 @@ def clodDetectObjects(image, cascade: Cascade, env: Environment, min_window_size
                       min_neighbors: int = 0, flags: int = 0, use_opencl: bool = True,
                       vj_flags: int = 0) -> DetectResult:
     """clod.h:72-81 / clod.cpp:1339-1356 with use_opencl=CL_TRUE → clodDetectObjectsOpenCL
-    (clod.cpp:1176-1336).  `image` may also be a batch (see Environment.detect)."""
+    (clod.cpp:1176-1336).  `image` may also be a batch (see Environment.detect).  At the reference's own signature a cascade
+    with tilted features behaves as in the reference — precomputeFeatures never reads the flag (clod.cpp:448-492), the
+    rectangles count as upright ones — where Environment.detect refuses it unless VJ_FLAG_TILTED_AS_UPRIGHT is given."""
+    vj_flags |= VJ_FLAG_TILTED_AS_UPRIGHT
     if not use_opencl:
         # the reference's CPU evaluators (clod.cpp:1358-1499) return the skip-thinned window set; the device computes the
         # same set.  The block variant (clod.cpp:821-1173) keeps `step` in double: two more grids (VJ_FLAG_GRID_F64).

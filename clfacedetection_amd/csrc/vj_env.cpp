@@ -82,6 +82,13 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         set_error("cascade has %zu stages; at most %d are supported", c.stages.size(), VJ_MAX_STAGES);
         return VJ_ERR_LIMIT;
     }
+    if (!(p.flags & VJ_FLAG_TILTED_AS_UPRIGHT))
+        for (const auto& nd : c.nodes)
+            if (nd.tilted) {
+                set_error("the cascade has tilted features: the clod profile would evaluate them as upright rectangles like the reference "
+                          "(clod.cpp:448-492 never reads the flag) — pass VJ_FLAG_TILTED_AS_UPRIGHT for that, or use vj_detect_opencv");
+                return VJ_ERR_UNSUPPORTED;
+            }
     pl->prog = build_stage_program(c);
     const uint32_t skip_mode = p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW);
     pl->skip_mode = skip_mode;
@@ -603,7 +610,7 @@ static int small_frame_class(const vj_env* e, int W, int H, int n_frames) {
 // The workload whose chain balance is being found (or was found) by feedback: batches of >= 8 frames through vj_detect.
 static vj_env::BalanceKey balance_key(const vj_env* e, const vj_cascade* c, int W, int H, const vj_params& p, int n_frames) {
     return vj_env::BalanceKey(vj_env::PlanKey(c->content_hash, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
-                                              p.scale_mask[1], p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64), 0u),
+                                              p.scale_mask[1], p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64 | VJ_FLAG_TILTED_AS_UPRIGHT), 0u),
                               e->balance_class(n_frames));
 }
 
@@ -809,7 +816,7 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
     int small = small_frame_class(e, W, H, n_frames);
     if (small == 0 && choice.thr == 1 && !e->tile_thresholds_set) small = 3;   // the feedback's lower thresholds
     vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
-                        p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64)) | ((uint32_t)small << 8), f2u(split));
+                        p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64 | VJ_FLAG_TILTED_AS_UPRIGHT)) | ((uint32_t)small << 8), f2u(split));
     auto it = e->plans.find(key);
     if (it != e->plans.end()) {
         it->second->last_used = ++e->plan_tick;

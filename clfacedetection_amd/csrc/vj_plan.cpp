@@ -86,10 +86,8 @@ int build_node_table_stride(const vj_cascade& c, uint32_t stride, const vj_scale
             const vj_node_desc& nd = c.nodes[td.first_node + k];
             NodeRec& r = recs[td.first_node + k];
             memset(&r, 0, sizeof(r));
-            if (nd.tilted) {
-                set_error("tilted features are not supported (clod ignores the flag, clod.cpp:460)");
-                return VJ_ERR_UNSUPPORTED;
-            }
+            // (nd.tilted is not read: precomputeFeatures takes the rectangles as they are, clod.cpp:448-492; build_plan refuses such
+            // a cascade unless the caller asks for the reference's reading with VJ_FLAG_TILTED_AS_UPRIGHT)
             if (nd.rect[0].weight == 0.0f || nd.rect[1].weight == 0.0f) {
                 set_error("node %d: rect 0 and rect 1 must both be weighted (clod.cl:60-68 reads both)",
                           td.first_node + k);

@@ -100,6 +100,9 @@ CLODDetectObjectsResult clodDetectObjects(const IplImage* image, const CvHaarCla
     p.max_w = max_window_size.width;
     p.max_h = max_window_size.height;
     p.min_neighbors = min_neighbors;   // 0 in the demo (main.cpp:165); != 0: grouped as cv::groupRectangles does
+    // at the reference's own signature a cascade with tilted features behaves as in the reference: precomputeFeatures never reads
+    // the flag (clod.cpp:448-492), the rectangles count as upright ones (vj_detect itself refuses such a cascade without this)
+    p.flags |= VJ_FLAG_TILTED_AS_UPRIGHT;
     if (!use_opencl) {                 // the CPU variants' window sets (clod.cpp:1358-1499), still computed on the device
         p.flags |= (flags & CLOD_PER_STAGE_ITERATIONS) ? VJ_FLAG_SKIP_LIST : VJ_FLAG_SKIP_ROW;
         if (flags & CLOD_BLOCK_IMPLEMENTATION) p.flags |= VJ_FLAG_GRID_F64;   // clodDetectObjectsBlock: `step` is a double (clod.cpp:862)

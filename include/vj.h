@@ -122,6 +122,13 @@ enum {
                                        double (:862): grid ends lrint((W - w) / step) in f64 (:890-891) and
                                        positions from the f64 product — lrint in the row loop (:941-942),
                                        round() in the per-stage lists (:1034): a third and a fourth grid       */
+    VJ_FLAG_TILTED_AS_UPRIGHT = 1u << 5, /* a cascade with <tilted>1 features in the clod profile: precomputeFeatures
+                                       never reads the flag (clod.cpp:448-492 takes haar_feature[0]'s rectangles as they are),
+                                       so the reference evaluates such rectangles as UPRIGHT ones — 12 of the 19 cascades
+                                       it ships have them.  Without this flag the clod-profile entry points refuse the
+                                       cascade (VJ_ERR_UNSUPPORTED: the result is not a meaningful detection); with it they
+                                       reproduce the reference's arithmetic.  vj_detect_opencv evaluates tilted features on
+                                       the tilted integral as OpenCV does and ignores the flag.                            */
 };
 
 typedef struct vj_params {

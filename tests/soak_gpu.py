@@ -18,7 +18,7 @@ try:
 except Exception:
     pass
 from cases import make_frame  # noqa: E402
-from clfacedetection_amd import (VJ_FLAG_COUNTERS, VJ_FLAG_GRID_F64, VJ_FLAG_SKIP_LIST, VJ_FLAG_SKIP_ROW, Cascade, Environment,  # noqa: E402
+from clfacedetection_amd import (VJ_FLAG_COUNTERS, VJ_FLAG_GRID_F64, VJ_FLAG_SKIP_LIST, VJ_FLAG_SKIP_ROW, VJ_FLAG_TILTED_AS_UPRIGHT, Cascade, Environment,  # noqa: E402
                                  default_params)
 from clfacedetection_amd.api import DATA_DIR  # noqa: E402
 from oracle.oracle import Oracle, load_vjc  # noqa: E402
@@ -29,7 +29,11 @@ max_w = int(sys.argv[3]) if len(sys.argv) > 3 else 900      # frame sizes are dr
 max_h = int(sys.argv[4]) if len(sys.argv) > 4 else 600
 o = Oracle()
 env = Environment(0)
-NAMES = ["frontalface_alt", "frontalface_default", "frontalface_alt2", "eye", "frontalface_alt_tree", "fullbody", "eye_tree_eyeglasses"]
+NAMES = ["frontalface_alt", "frontalface_default", "frontalface_alt2", "eye", "frontalface_alt_tree", "fullbody", "eye_tree_eyeglasses",
+         # the other cascades the reference ships: non-square windows, tilted features (the clod profile reads them as upright rectangles
+         # like the reference: VJ_FLAG_TILTED_AS_UPRIGHT), two-node trees with tilted nodes
+         "lefteye_2splits", "lowerbody", "mcs_eyepair_big", "mcs_eyepair_small", "mcs_lefteye", "mcs_mouth", "mcs_nose", "mcs_righteye",
+         "mcs_upperbody", "profileface", "righteye_2splits", "upperbody"]
 CASC = {n: (Cascade.load(n), load_vjc(os.path.join(DATA_DIR, f"haarcascade_{n}.vjc"))) for n in NAMES}
 TUNABLES = [("tile_split", ["0", "0.5", "1.3", "0,1.75,2"]), ("blocks_per_cu", ["1", "3", "8"]), ("gather_pairs", ["-1", "0", "2"]),
             ("sp_tail_max", ["0", "16", "48"]), ("thin_pass_spread", ["0", "1"]), ("tree_split_queues", ["0", "1"]), ("concurrent", ["0", "1"]),
@@ -65,8 +69,9 @@ while time.time() < t_end:
     c, a = CASC[name]
     linear = bool(np.all(a.stage_next == -1))
     tilted = bool(a.node_tilted.any())
-    if tilted and mode != "opencv":
-        mode = "opencv"
+    if tilted and mode not in ("opencv", "grid", "skip_list", "skip_row", "block_row", "block_list"):
+        mode = "opencv" if rng.random() < 0.5 else "grid"
+    tflag = VJ_FLAG_TILTED_AS_UPRIGHT if tilted else 0
     if mode in ("skip_list", "skip_row", "block_row", "block_list") and not linear:
         mode = "grid"
     w = int(rng.integers(c.info.win_w + 11, max_w))
@@ -103,7 +108,7 @@ while time.time() < t_end:
             mn = (0, 0) if rng.random() < 0.6 else (int(rng.integers(20, 70)),) * 2
             mx = (0, 0) if rng.random() < 0.7 else (int(rng.integers(80, 300)),) * 2
             sf = [1.1, 1.2, 1.05, 1.3, 1.5][int(rng.integers(0, 5))]
-            flags = VJ_FLAG_COUNTERS | {"grid": 0, "skip_list": VJ_FLAG_SKIP_LIST, "skip_row": VJ_FLAG_SKIP_ROW,
+            flags = VJ_FLAG_COUNTERS | tflag | {"grid": 0, "skip_list": VJ_FLAG_SKIP_LIST, "skip_row": VJ_FLAG_SKIP_ROW,
                                         "block_row": VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64, "block_list": VJ_FLAG_SKIP_LIST | VJ_FLAG_GRID_F64}[mode]
             p = default_params(flags=flags, min_w=mn[0], min_h=mn[1], max_w=mx[0], max_h=mx[1], scale_factor=sf)
             r = env.detect(c, [img] * nb if nb > 1 else img, p)
