@@ -143,12 +143,16 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
     // at 3 x 1536, frontalface_default 51.4 / 57.1, 256 x 720p 112.7 / 136.9 —, multi-node trees the other way round: frontalface_alt2 99.3 / 77.5;
     // two-node trees with both nodes fetched at once (CvArgs::tree2, #5d): 2 x 1536 69.9 ms against 80.9 at 3 x 1536)
     const bool rows_tree2 = pl->tree2 && !is_tree && !has_tilted && e->cv_tree2;
-    const int lin_blocks = e->cv_row_blocks > 0 ? e->cv_row_blocks : trees && !rows_tree2 ? 3 : 2;
-    const int lin_min_windows = e->cv_tile_min_windows > 0 ? e->cv_tile_min_windows : trees ? 1536 : 2048;
+    // (cascades with tilted features, #12: a tile holds two images, so the shapes that fit are smaller — and the row kernel they relieve is 2-3x
+    // the tiles' cost per window: two workgroups x tiles of >= 512 windows, `fullbody` 16 x 1080p 28-29 ms against 40.8 with every tile of
+    // >= 2048 windows refused, `upperbody` 50.7 / 96.6, `mcs_righteye`'s kernels 30.9 / 72.4)
+    const bool tilt_tiles = has_tilted && e->cv_tiles_tilted && !is_tree;
+    const int lin_blocks = e->cv_row_blocks > 0 ? e->cv_row_blocks : tilt_tiles ? 2 : trees && !rows_tree2 ? 3 : 2;
+    const int lin_min_windows = e->cv_tile_min_windows > 0 ? e->cv_tile_min_windows : tilt_tiles ? 512 : trees ? 1536 : 2048;
     pl->row_blocks = is_tree ? e->cv_row_blocks_tree : lin_blocks;
     // a call of <= 4 frames is bound by latency, not by the balance of two saturated chains: one row-kernel workgroup per CU
     // and every scale that has a tile of 512 windows on tiles (one 1080p frame: 2.4 -> 2.0 ms)
-    int min_windows = is_tree ? e->cv_tile_min_windows_tree : lin_min_windows, min_windows0 = e->cv_tile_min_windows0;
+    int min_windows = is_tree ? e->cv_tile_min_windows_tree : lin_min_windows, min_windows0 = tilt_tiles ? std::min(e->cv_tile_min_windows0, 512) : e->cv_tile_min_windows0;
     if (small_batch && !is_tree) {
         pl->row_blocks = 1;
         min_windows = std::min(min_windows, 512);
@@ -255,7 +259,11 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
         // windows (tw divides 64, so a tile row never straddles a word of the reject / visited bitmap); its footprint is
         // the span of its window origins plus the furthest corner any feature or the equRect reaches.  Two LDS classes
         // like the clod profile's tiles: two workgroups per CU or one, next to one workgroup of cv_profile_pass.
-        if (e->cv_tiles && (!trees || (tree2 && !is_tree)) && (!is_tree || tree_prefix != 0u) && !has_tilted && sd.end_x < 65536u &&
+        // Tilted features (round 4): the tile's footprint of the TILTED integral is staged right behind the sum's (same origin, pitch and
+        // rows: a tilted rectangle's corners (y, x), (y + h, x - h), (y + w, x + w), (y + w + h, x + w - h) lie inside the window's box), a
+        // tilted node's record carries that distance in its corner offsets, and the kernel's node code does not change.
+        const bool tiles_tilted = has_tilted && e->cv_tiles_tilted && !is_tree;
+        if (e->cv_tiles && (!trees || (tree2 && !is_tree)) && (!is_tree || tree_prefix != 0u) && (!has_tilted || tiles_tilted) && sd.end_x < 65536u &&
             sd.end_y < 65536u) {
             uint32_t reach_x = (uint32_t)(ex + ew), reach_y = (uint32_t)(ex + eh);
             for (size_t n = 0; n < n_nodes; ++n) {
@@ -263,10 +271,17 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
                 for (int q = 0; q < 3; ++q)
                     if (q < 2 || r.w[2] != 0.0f) {
                         const uint32_t p0 = r.lt[q] / 4u;
-                        reach_x = std::max(reach_x, p0 % stride + r.da[q] / 4u);
-                        reach_y = std::max(reach_y, p0 / stride + (r.db[q] / 4u) / stride);
+                        if (r.flags & CV_NODE_TILTED) {   // da = h * (stride - 1), db = w * (stride + 1): rightmost corner x + w, lowest y + w + h
+                            const uint32_t hh = (r.da[q] / 4u) / (stride - 1u), ww = (r.db[q] / 4u) / (stride + 1u);
+                            reach_x = std::max(reach_x, p0 % stride + ww);
+                            reach_y = std::max(reach_y, p0 / stride + ww + hh);
+                        } else {
+                            reach_x = std::max(reach_x, p0 % stride + r.da[q] / 4u);
+                            reach_y = std::max(reach_y, p0 / stride + (r.db[q] / 4u) / stride);
+                        }
                     }
             }
+            const uint32_t images = has_tilted ? 2u : 1u;   // LDS images per tile
             static const uint32_t kTw[] = {64, 32, 16}, kTh[] = {32, 24, 16, 12, 8, 4};
             // LDS budget of a CU: the row kernel's workgroups (20 KiB each) stay resident next to two tile workgroups
             // of class 0 or one of class 1; a tile workgroup also owns CVT_LDS_HEADER bytes of queues
@@ -279,7 +294,7 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
                     for (uint32_t th : kTh) {
                         const uint32_t pitch = (((uint32_t)std::ceil((double)(tw - 1) * sd.ystep) + 3u + reach_x) + 3u) & ~3u;
                         const uint32_t trows = (uint32_t)std::ceil((double)(th - 1) * sd.ystep) + 3u + reach_y;
-                        if ((uint64_t)pitch * trows * 4u > class_bytes[cls]) continue;
+                        if ((uint64_t)pitch * trows * 4u * images > class_bytes[cls]) continue;
                         const uint32_t nwin = std::min(tw, sd.end_x) * std::min(th, sd.end_y);
                         if (nwin > best_n) { best_n = nwin; b_tw = tw; b_th = th; b_pitch = pitch; b_rows = trows; }
                     }
@@ -302,9 +317,17 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
                     trec[n] = recs[n];
                     for (int q = 0; q < 3; ++q)
                         if (q < 2 || recs[n].w[2] != 0.0f) {
-                            const uint32_t p0 = recs[n].lt[q] / 4u, hh = (recs[n].db[q] / 4u) / stride;
-                            trec[n].lt[q] = ((p0 / stride) * b_pitch + p0 % stride) * 4u;
-                            trec[n].db[q] = hh * b_pitch * 4u;
+                            const uint32_t p0 = recs[n].lt[q] / 4u;
+                            if (recs[n].flags & CV_NODE_TILTED) {   // in the tilted image behind the sum image, corner steps in the tile's pitch
+                                const uint32_t hh = (recs[n].da[q] / 4u) / (stride - 1u), ww = (recs[n].db[q] / 4u) / (stride + 1u);
+                                trec[n].lt[q] = (b_pitch * b_rows + (p0 / stride) * b_pitch + p0 % stride) * 4u;
+                                trec[n].da[q] = (hh * b_pitch - hh) * 4u;
+                                trec[n].db[q] = (ww * b_pitch + ww) * 4u;
+                            } else {
+                                const uint32_t hh = (recs[n].db[q] / 4u) / stride;
+                                trec[n].lt[q] = ((p0 / stride) * b_pitch + p0 % stride) * 4u;
+                                trec[n].db[q] = hh * b_pitch * 4u;
+                            }
                         }
                 }
             }
@@ -335,7 +358,7 @@ static int build_cv_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_
             for (size_t k = 0; k < hs.size(); ++k) {
                 const CvScaleDev& sd = scales[k];
                 if (sd.tile_th == 0u || tile_class[k] != cls) continue;
-                lds = std::max(lds, (uint32_t)CVT_LDS_HEADER + sd.tile_pitch * sd.tile_rows * 4u);
+                lds = std::max(lds, (uint32_t)CVT_LDS_HEADER + sd.tile_pitch * sd.tile_rows * 4u * (has_tilted ? 2u : 1u));
                 for (uint32_t iy0 = 0; iy0 < sd.end_y; iy0 += sd.tile_th)
                     for (uint32_t ix0 = 0; ix0 < sd.end_x; ix0 += sd.tile_tw) tiles.push_back(UnitDev{(uint32_t)k, ix0 | (iy0 << 16), 0, 0});
             }
@@ -588,6 +611,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 memset(&t, 0, sizeof(t));
                 t.tq_shift = chain_pass ? (uint32_t)pl->tq_shift : 0xffffffffu;   // one sub-queue per scale, or one flat queue (cv_tree_walk)
                 t.sum = a.sum;
+                t.tilted = a.tilted;
                 t.sqsum = a.sqsum;
                 t.table = a.table;
                 t.scales = a.scales;
@@ -694,6 +718,7 @@ int vj_detect_opencv(vj_env* e, const vj_cascade* c, const vj_image* frames, int
                 CvTileArgs t;
                 memset(&t, 0, sizeof(t));
                 t.sum = a.sum;
+                t.tilted = a.tilted;
                 t.sqsum = a.sqsum;
                 t.table = a.table;
                 t.scales = a.scales;

@@ -1,5 +1,6 @@
 // OpenCV arithmetic profile on LDS tiles (gfx950): the small scales of cvHaarDetectObjects' scale-cascade path
-// (tempcv.cpp:1116-1185 -> cvRunHaarClassifierCascadeSum :795-972, stump cascades, linear stages, upright features)
+// (tempcv.cpp:1116-1185 -> cvRunHaarClassifierCascadeSum :795-972; stumps and two-node trees, linear stages and stage-tree prefixes,
+// upright features and — the tilted integral staged behind the sum — tilted ones)
 // with the rectangle corners gathered from a tile of the sum image staged in LDS instead of through the
 // texture-address unit — the machinery of the clod profile's tile kernel (vj_kernels.hip: cascade_tile_pass) on this
 // profile's arithmetic: f64 variance norm factor and stage sums, node products per stage as tempcv.cpp's scalar
@@ -460,6 +461,18 @@ __global__ __launch_bounds__(CVT_WAVES * 64) void cv_tile_pass(CvTileArgs a) {
                 if (c0 + lane * 4u < pitch)
                     __builtin_amdgcn_raw_ptr_buffer_load_lds(sum_f, (__attribute__((address_space(3))) uint32_t*)(lds_img + rr * pitch + c0),
                                                              16, lane * 16u, soff, 0, 0);
+            }
+        }
+        if (a.tilted != nullptr) {   // ... and of the tilted integral, right behind it (tilted nodes' records carry the distance)
+            const rsrc_t tilt_f = make_rsrc(a.tilted + frame_off, frame_bytes4);
+            for (uint32_t rr = wib; rr < rows; rr += (uint32_t)CVT_WAVES) {
+                const uint32_t g_row = ((y0 + rr) * a.stride + x0) * 4u;
+                for (uint32_t c0 = 0; c0 < pitch; c0 += 256u) {
+                    const uint32_t soff = __builtin_amdgcn_readfirstlane(g_row + c0 * 4u);
+                    if (c0 + lane * 4u < pitch)
+                        __builtin_amdgcn_raw_ptr_buffer_load_lds(tilt_f, (__attribute__((address_space(3))) uint32_t*)(lds_img + (rows + rr) * pitch + c0),
+                                                                 16, lane * 16u, soff, 0, 0);
+                }
             }
         }
         // while the tile is in flight: this wave's four window rows (one per chunk, lane = column), the windows the walk

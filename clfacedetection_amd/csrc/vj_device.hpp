@@ -427,6 +427,7 @@ constexpr int CVT_WS_MAX = 512;         // windows a tile may carry into the wav
 constexpr int CVT_LDS_HEADER = CVT_WAVES * CVT_WAVE_CAP * 12 + 512;   // offset queue (u32) + norm-factor queue (f64) + counters + 32 reject words, bytes
 struct CvTileArgs {
     const uint32_t* sum;
+    const uint32_t* tilted;      // tilted integral images, same geometry (null: the cascade has no tilted features): staged behind the sum tile
     const uint64_t* sqsum;
     const uint32_t* table;       // CvNodeRec[] (the tile scales' records carry offsets in the tile's pitch)
     const CvScaleDev* scales;

@@ -2088,6 +2088,12 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
         (strcmp(key, "cv_tree_chunk") == 0 ? e->cv_tree_chunk : e->cv_tree_chain_blocks) = std::max(1, atoi(value));
         return VJ_OK;
     }
+    if (strcmp(key, "cv_tiles_tilted") == 0) {   // (part of the plan: cached plans are dropped)
+        e->cv_tiles_tilted = atoi(value) != 0;
+        HIP_TRY(hipStreamSynchronize(e->stream));
+        drop_plans(e);
+        return VJ_OK;
+    }
     if (strcmp(key, "cv_tree2") == 0) {   // (the default balance depends on it: cached plans are dropped)
         e->cv_tree2 = atoi(value) != 0;
         HIP_TRY(hipStreamSynchronize(e->stream));

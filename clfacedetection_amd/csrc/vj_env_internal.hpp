@@ -291,6 +291,7 @@ struct vj_env {
     bool cv_pairs = false;            // ... linear cascades' row kernel: two stumps per step in the sweeps of its queue
     int cv_tail_max = 64;             // ... a population of at most this many windows evaluates a stage stump-parallel (<= 64)
     int cv_tree_chunk = 64, cv_tree_chain_blocks = 2;   // ... windows per chunk and workgroups per CU of cv_tree_chain_pass
+    bool cv_tiles_tilted = true;      // ... cascades with tilted features on LDS tiles too (the tilted integral's tile staged behind the sum's)
     bool cv_tree2 = true;             // ... cascades of two-node trees: the row kernel fetches both nodes of a tree at once
     int cv_row_band_px = 128;         // ... the row kernel's rows in band-major order, bands of this many pixels (0: scale after scale)
     bool cv_tree_chains = true;       // ... stage trees made of chains: compacting chain sweeps (0: the per-lane target-stage walk)

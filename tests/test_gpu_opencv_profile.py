@@ -215,6 +215,10 @@ def test_plan_cache_of_the_profile(env, oracle, cascades):
     ("frontalface_alt_tree", "faces", 36, 540, 960, 2),       # stage tree: prefix on tiles, cv_tree_walk, skip_resolve, cv_tree_emit
     ("frontalface_alt_tree", "noise", 37, 300, 420, 3),       # (the counted call of a stage tree walks the rows: the plain one is the tile path)
     ("frontalface_alt_tree", "smooth", 38, 400, 700, 1),
+    ("fullbody", "blocks", 42, 540, 960, 2),                  # tilted features: the tilted integral's tile staged behind the sum's
+    ("mcs_mouth", "noise", 43, 480, 640, 3),                  # 25 x 15 window, 223 tilted nodes
+    ("upperbody", "smooth", 45, 720, 1280, 1),
+    ("lefteye_2splits", "faces", 44, 540, 960, 2),            # two-node trees with tilted nodes
 ])
 def test_lds_tile_path_equals_the_row_kernel_and_the_oracle(env, oracle, cascades, casc, kind, seed, h, w, batch):
     """The profile's small scales run on LDS tiles (vj_cv_tile.hip: reject bits of stage 0, skip_resolve, the cascade on
@@ -245,8 +249,8 @@ def test_lds_tile_path_equals_the_row_kernel_and_the_oracle(env, oracle, cascade
             assert np.array_equal(env.detect_opencv(c, frames).rects, tiled.rects)
         finally:
             env.configure("cv_tree_queue_cap", 0)
-    defaults = {"cv_tile_ws_max": 512, "cv_tile_min_windows": -1, "cv_tile_min_windows0": 2048, "cv_row_blocks": -1, "concurrent": 1, "cv_row_band_px": 128, "cv_tree2": 1}
-    for setting in ({"cv_tile_ws_max": 64}, {"cv_tile_ws_max": 0}, {"cv_tile_min_windows": 64, "cv_tile_min_windows0": 64}, {"cv_row_band_px": 0}, {"cv_row_band_px": 40}, {"cv_tree2": 0},
+    defaults = {"cv_tile_ws_max": 512, "cv_tile_min_windows": -1, "cv_tile_min_windows0": 2048, "cv_row_blocks": -1, "concurrent": 1, "cv_row_band_px": 128, "cv_tree2": 1, "cv_tiles_tilted": 1}
+    for setting in ({"cv_tile_ws_max": 64}, {"cv_tile_ws_max": 0}, {"cv_tile_min_windows": 64, "cv_tile_min_windows0": 64}, {"cv_row_band_px": 0}, {"cv_row_band_px": 40}, {"cv_tree2": 0}, {"cv_tiles_tilted": 0},
                     {"cv_row_blocks": 1, "cv_tile_min_windows0": 512, "cv_tile_min_windows": 512}, {"concurrent": 0}):
         try:                         # finish thresholds, small tiles of both LDS classes, other occupancies, one stream: same result
             for key, val in setting.items():
