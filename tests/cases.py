@@ -26,6 +26,14 @@ DETECT_CASES = [
     ("alt2_smooth_300", "frontalface_alt2", "smooth", 62, 300, 400, (0, 0), (0, 0), False),
     ("alt_tree_noise_240", "frontalface_alt_tree", "noise", 71, 240, 320, (0, 0), (0, 0), False),
     ("alt_tree_blocks_300", "frontalface_alt_tree", "blocks", 72, 300, 400, (0, 0), (0, 0), False),
+    # cascades the reference ships that the configs do not name: non-square base windows, and tilted features, which the clod
+    # path reads as upright rectangles (clod.cpp:448-492; the GPU test calls at the reference's signature, which passes the flag)
+    ("eyepair_small_noise", "mcs_eyepair_small", "noise", 91, 200, 320, (0, 0), (0, 0), False),     # 22 x 5
+    ("eyepair_big_blocks", "mcs_eyepair_big", "blocks", 92, 240, 400, (0, 0), (0, 0), False),       # 45 x 11
+    ("lowerbody_blocks", "lowerbody", "blocks", 93, 240, 320, (0, 0), (0, 0), False),               # 19 x 23
+    ("profileface_noise", "profileface", "noise", 94, 240, 320, (0, 0), (0, 0), False),
+    ("righteye_2splits_smooth", "righteye_2splits", "smooth", 95, 240, 320, (0, 0), (0, 0), False), # two-node trees with tilted nodes
+    ("mcs_mouth_minmax", "mcs_mouth", "blocks", 96, 300, 400, (30, 18), (150, 90), False),          # 25 x 15, size limits
 ]
 # the headline pin: the survey's recorded reference run
 HEADLINE_CASE = ("alt_xs12345_1080", "frontalface_alt", "xorshift", 12345, 1080, 1920, (0, 0), (0, 0), False)
@@ -40,6 +48,11 @@ MODE_CASES = [  # (id, cascade, generator, seed, height, width)
     ("m_alt_tree_blocks", "frontalface_alt_tree", "blocks", 72, 300, 400),
     ("m_fullbody_noise", "fullbody", "noise", 81, 240, 320),
     ("m_eyeglasses_smooth", "eye_tree_eyeglasses", "smooth", 84, 240, 320),
+    ("m_mcs_nose_noise", "mcs_nose", "noise", 85, 200, 260),                 # 18 x 15, 990 tilted nodes
+    ("m_upperbody_blocks", "upperbody", "blocks", 86, 240, 320),             # 22 x 18
+    ("m_profileface_smooth", "profileface", "smooth", 87, 240, 320),         # upright stumps: skip modes too
+    ("m_lefteye_2splits_noise", "lefteye_2splits", "noise", 88, 240, 320),
+    ("m_eyepair_big_blocks", "mcs_eyepair_big", "blocks", 89, 200, 400),     # 45 x 11
 ]
 
 GROUP_CASES = [  # (id, first cascade, second cascade, seed, height, width, min_neighbors): drawn faces (synth kind "faces")
