@@ -393,7 +393,7 @@ int vj_cascade_load_xml(const char* path, vj_cascade** out) {
     std::string buf;
     int rc = read_file(path, &buf);
     if (rc) return rc;
-    XmlParser xp{buf.data(), buf.data() + buf.size()};
+    XmlParser xp{buf.data(), buf.data() + buf.size(), std::string(), false, std::string()};
     if (!xp.skip_misc()) { set_error("%s: %s", path, xp.err.c_str()); return VJ_ERR_PARSE; }
     auto root = xp.element();
     if (!root) { set_error("%s: %s", path, xp.err.c_str()); return VJ_ERR_PARSE; }

@@ -1139,7 +1139,7 @@ static int enqueue_prepare(vj_env* e, Lane* L, Plan* pl, const vj_image* frames,
 
 // Enqueue every cascade launch of the batch whose integral images are (being) computed, then the asynchronous
 // read-back of its counters and first detections.  Nothing here waits for the device.
-static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int H, const vj_params& p) {
+static int enqueue_cascade(vj_env* e, Lane* L, Plan* pl, int W, int /*H*/, const vj_params& p) {
     int rc;
     const int nf = L->nf;
     const size_t n_pass = pl->pass_bounds.size() - 1;
@@ -1663,7 +1663,9 @@ static int check_params(const vj_params& p) {
     return VJ_OK;
 }
 
-static void drop_plans(vj_env* e);
+extern "C" {
+static void drop_plans(vj_env* e);   // (defined inside the extern "C" block below: the same language linkage here)
+}
 
 // Arguments of the region pass (roi_plan_units + cascade_roi_pass): `second` inside regions of the nf frames whose integral
 // images sit in e->d_sum / e->d_sqsum.  The region list is e->d_rois (max_rois entries), its length on the device at
