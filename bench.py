@@ -91,8 +91,8 @@ def main() -> int:
     ap.add_argument("--height", type=int, default=1080)
     ap.add_argument("--cascade", default="frontalface_alt")
     ap.add_argument("--cpu-frames", type=int, default=8, help="frames of the batch timed on the CPU oracle (0 = skip)")
-    ap.add_argument("--extras", "--config", default="2,3h,4,5", help="other BASELINE configs measured into `extra` "
-                    "(2, 3h = config 3 from host frames, 4, 5; \"\" = none)")
+    ap.add_argument("--extras", "--config", default="1,2,3h,4,5", help="other BASELINE configs measured into `extra` "
+                    "(1 = the reference's 640 x 480 case, 2, 3h = config 3 from host frames, 4, 5; \"\" = none)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the N > 1 path on a box with fewer GPUs than ranks)")
     ap.add_argument("--share-gpu", action="store_true", help="rehearsal: every rank uses cuda:0")
@@ -483,6 +483,27 @@ def run_extras(env, casc_alt, frames_h, which, torch) -> dict:
     from clfacedetection_amd import Cascade, DeviceFrames, default_params, synth
     extra = {}
     pct = lambda v, q: float(np.percentile(np.asarray(v), q))
+    if "1" in which:
+        # config 1 (BASELINE configs[0]): the reference's own CPU-runnable case — one 640 x 480 frame, frontalface_default, scaleFactor 1.1,
+        # minNeighbors 3 — as the device answers it: host frame in, grouped rectangles out (clod arithmetic; the OpenCV profile beside it)
+        c1 = Cascade.load("frontalface_default")
+        f1 = synth.batch(8, 480, 640, seed0=101, kinds=("faces", "noise", "smooth", "blocks"))
+        p1 = default_params(min_neighbors=3)
+        for _ in range(5):
+            env.detect(c1, f1[0], p1)
+            env.detect_opencv(c1, f1[0], min_neighbors=3)
+        lat, lat_cv, n_out = [], [], 0
+        for i in range(60):
+            t = time.perf_counter()
+            r = env.detect(c1, f1[i % 8], p1)
+            lat.append((time.perf_counter() - t) * 1e3)
+            n_out += len(r.rects)
+            t = time.perf_counter()
+            env.detect_opencv(c1, f1[i % 8], min_neighbors=3)
+            lat_cv.append((time.perf_counter() - t) * 1e3)
+        extra["config1"] = {"workload": "1x640x480, frontalface_default, minNeighbors 3, host frame in -> grouped rects out, 60 calls",
+                            "latency_ms_p50": round(pct(lat, 50), 3), "latency_ms_p90": round(pct(lat, 90), 3),
+                            "opencv_profile_latency_ms_p50": round(pct(lat_cv, 50), 3), "grouped_rects_in_60_calls": n_out}
     if "2" in which:
         # config 2: one 1080p frame per call, the reference's per-frame pattern (main.cpp:159-184): host buffer in, rects out
         f = frames_h[0]
