@@ -856,6 +856,107 @@ int launch_tilted_integral(const TiltedArgs& a, void* stream_) {
     return (int)hipGetLastError();
 }
 
+// The same image without the row-by-row dependency (1080 barriers deep: 1.25 ms whatever the batch).  With zero outside the frame,
+//   A(x, y) = sum_k I(x - k, y - k)   (the "\" diagonal ending at (x, y)),    B(x, y) = sum_k I(x + k, y - k)   (the "/" diagonal),
+// the triangle with its apex at pixel (x, y) is the one with its apex at (x, y - 1) plus both diagonals through (x, y):
+//   Tri(x, y) = Tri(x, y - 1) + A(x, y) + B(x, y) - I(x, y),        tilted(X, Y) = Tri(X - 1, Y - 1)
+// — a column prefix of C = A + B - I, and A and B are column prefixes of the image sheared one way and the other.  Three prefix sums
+// over the rows, each in bands of 8 rows like the upright integral: per-band totals, an exclusive scan over the bands, the rows of a
+// band from its prefix.  Integer adds mod 2^32 in another order: the same image, bit for bit (vj_integral_tilted's tests compare
+// both kernels with the oracle's direct sum).  diag: [frame][band][2][W + H] (A by x - y + H - 1, B by x + y), col: [frame][band][W + 1].
+constexpr uint32_t TILT_ROWS = 8;
+__device__ __forceinline__ uint32_t tilt_px(const TiltedArgs& a, const uint8_t* img, int32_t x, int32_t y) {
+    if (x < 0 || y < 0 || x >= (int32_t)a.width || y >= (int32_t)a.height) return 0u;
+    return gray_at(img + (size_t)y * a.gray_stride, (uint32_t)x, a.channels);
+}
+
+__global__ __launch_bounds__(256) void tilt_diag_sums(TiltedArgs a, uint32_t* diag) {
+    const uint32_t D = a.width + a.height, i = blockIdx.x * 256u + threadIdx.x, band = blockIdx.y, frame = blockIdx.z;
+    if (i >= D) return;
+    const uint8_t* img = a.gray + (size_t)frame * a.gray_frame_bytes;
+    const uint32_t n_bands = (a.height + TILT_ROWS - 1u) / TILT_ROWS;
+    uint32_t sa = 0, sb = 0;
+    for (uint32_t r = 0; r < TILT_ROWS; ++r) {
+        const int32_t y = (int32_t)(band * TILT_ROWS + r);
+        sa += tilt_px(a, img, (int32_t)i - (int32_t)(a.height - 1u) + y, y);
+        sb += tilt_px(a, img, (int32_t)i - y, y);
+    }
+    uint32_t* d = diag + ((size_t)frame * n_bands + band) * 2u * D;
+    d[i] = sa;
+    d[D + i] = sb;
+}
+
+// exclusive prefix over the bands, in place: `n` values per band, `per_band` the distance between bands
+__global__ __launch_bounds__(256) void tilt_band_scan(uint32_t* v, uint32_t n, uint32_t per_band, uint32_t n_bands) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x, frame = blockIdx.y;
+    if (i >= n) return;
+    uint32_t* p = v + (size_t)frame * n_bands * per_band + i;
+    uint32_t s = 0;
+    for (uint32_t b0 = 0; b0 < n_bands; b0 += 8u) {   // eight bands' loads in flight per step
+        uint32_t t[8];
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) t[k] = b0 + k < n_bands ? p[(size_t)(b0 + k) * per_band] : 0u;
+#pragma unroll
+        for (uint32_t k = 0; k < 8u; ++k) {
+            if (b0 + k < n_bands) p[(size_t)(b0 + k) * per_band] = s;
+            s += t[k];
+        }
+    }
+}
+
+// C(xc, y) for the rows of one band: the diagonals' prefixes at the band's top edge plus their part inside the band
+template <typename F>
+__device__ __forceinline__ void tilt_band_rows(const TiltedArgs& a, const uint8_t* img, const uint32_t* d /* this band's diag block */, int32_t xc,
+                                               uint32_t band, F row) {
+    const uint32_t D = a.width + a.height;
+    const int32_t y0 = (int32_t)(band * TILT_ROWS);
+    for (uint32_t r = 0; r < TILT_ROWS && y0 + (int32_t)r < (int32_t)a.height; ++r) {
+        const int32_t y = y0 + (int32_t)r;
+        const int32_t ia = xc - y + (int32_t)(a.height - 1u), ib = xc + y;
+        uint32_t A = ia >= 0 && ia < (int32_t)D ? d[ia] : 0u, B = ib >= 0 && ib < (int32_t)D ? d[D + ib] : 0u;
+        for (int32_t k = 0; k <= (int32_t)r; ++k) {
+            A += tilt_px(a, img, xc - k, y - k);
+            B += tilt_px(a, img, xc + k, y - k);
+        }
+        row(y, A + B - tilt_px(a, img, xc, y));
+    }
+}
+
+__global__ __launch_bounds__(256) void tilt_col_sums(TiltedArgs a, const uint32_t* diag, uint32_t* col) {
+    const uint32_t ow = a.width + 1u, X = blockIdx.x * 256u + threadIdx.x, band = blockIdx.y, frame = blockIdx.z;
+    if (X >= ow) return;
+    const uint8_t* img = a.gray + (size_t)frame * a.gray_frame_bytes;
+    const uint32_t n_bands = (a.height + TILT_ROWS - 1u) / TILT_ROWS, D = a.width + a.height;
+    uint32_t s = 0;
+    tilt_band_rows(a, img, diag + ((size_t)frame * n_bands + band) * 2u * D, (int32_t)X - 1, band, [&](int32_t, uint32_t c) { s += c; });
+    col[((size_t)frame * n_bands + band) * ow + X] = s;
+}
+
+__global__ __launch_bounds__(256) void tilt_out_rows(TiltedArgs a, const uint32_t* diag, const uint32_t* col) {
+    const uint32_t ow = a.width + 1u, X = blockIdx.x * 256u + threadIdx.x, band = blockIdx.y, frame = blockIdx.z;
+    if (X >= ow) return;
+    const uint8_t* img = a.gray + (size_t)frame * a.gray_frame_bytes;
+    const uint32_t n_bands = (a.height + TILT_ROWS - 1u) / TILT_ROWS, D = a.width + a.height;
+    uint32_t* out = a.tilted + (size_t)frame * a.frame_elems;
+    if (band == 0u) out[X] = 0u;   // row 0
+    uint32_t acc = col[((size_t)frame * n_bands + band) * ow + X];
+    tilt_band_rows(a, img, diag + ((size_t)frame * n_bands + band) * 2u * D, (int32_t)X - 1, band, [&](int32_t y, uint32_t c) {
+        acc += c;
+        out[(size_t)(y + 1) * ow + X] = acc;   // tilted(X, Y = y + 1) = Tri(X - 1, y)
+    });
+}
+
+int launch_tilted_bands(const TiltedArgs& a, uint32_t* diag, uint32_t* col, void* stream_) {
+    hipStream_t stream = (hipStream_t)stream_;
+    const uint32_t n_bands = (a.height + TILT_ROWS - 1u) / TILT_ROWS, D = a.width + a.height, ow = a.width + 1u;
+    hipLaunchKernelGGL(tilt_diag_sums, dim3((D + 255u) / 256u, n_bands, a.n_frames), dim3(256), 0, stream, a, diag);
+    hipLaunchKernelGGL(tilt_band_scan, dim3((2u * D + 255u) / 256u, a.n_frames), dim3(256), 0, stream, diag, 2u * D, 2u * D, n_bands);
+    hipLaunchKernelGGL(tilt_col_sums, dim3((ow + 255u) / 256u, n_bands, a.n_frames), dim3(256), 0, stream, a, (const uint32_t*)diag, col);
+    hipLaunchKernelGGL(tilt_band_scan, dim3((ow + 255u) / 256u, a.n_frames), dim3(256), 0, stream, col, ow, ow, n_bands);
+    hipLaunchKernelGGL(tilt_out_rows, dim3((ow + 255u) / 256u, n_bands, a.n_frames), dim3(256), 0, stream, a, (const uint32_t*)diag, (const uint32_t*)col);
+    return (int)hipGetLastError();
+}
+
 // ------------------------------------------------------------------------ gray image
 // clifGrayscale (clif.h:55-58 -> cvCvtColor BGR2GRAY): the gray image the integral kernels see, as its own output.
 __global__ __launch_bounds__(256) void gray_rows(TiltedArgs a, uint8_t* dst, uint32_t dst_stride) {

@@ -961,7 +961,15 @@ int enqueue_tilted(vj_env* e, const uint8_t* d_gray, size_t frame_bytes, int str
     ta.n_frames = (uint32_t)frames;
     ta.frame_elems = fe;
     ta.tilted = (uint32_t*)e->d_tilted.p;
-    const int hrc = launch_tilted_integral(ta, e->stream);
+    int hrc;
+    if (e->tilted_bands) {
+        const size_t n_bands = ((size_t)H + 7u) / 8u;
+        if ((rc = e->d_tilt_diag.ensure((size_t)frames * n_bands * 2u * (size_t)(W + H) * 4u))) return rc;
+        if ((rc = e->d_tilt_col.ensure((size_t)frames * n_bands * (size_t)(W + 1) * 4u))) return rc;
+        hrc = launch_tilted_bands(ta, (uint32_t*)e->d_tilt_diag.p, (uint32_t*)e->d_tilt_col.p, e->stream);
+    } else {
+        hrc = launch_tilted_integral(ta, e->stream);
+    }
     if (hrc) {
         set_error("tilted integral launch failed (width %d): %s", W, hipGetErrorString((hipError_t)hrc));
         return hrc == (int)hipErrorInvalidValue ? VJ_ERR_LIMIT : VJ_ERR_HIP;
@@ -1959,7 +1967,7 @@ void vj_env_destroy(vj_env* e) {
     (void)hipSetDevice(e->device);
     if (e->stream) (void)hipStreamSynchronize(e->stream);
     drop_plans(e);
-    for (DevBuf* b : {&e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_tilted, &e->d_out,
+    for (DevBuf* b : {&e->d_sum, &e->d_sqsum, &e->d_band_sum, &e->d_band_sq, &e->d_band_sqp, &e->d_tilted, &e->d_tilt_diag, &e->d_tilt_col, &e->d_out,
                       &e->d_skip_bits, &e->d_rois, &e->d_roi_units, &e->d_roi_det, &e->d_roi_tiles, &e->d_group, &e->d_cv_det, &e->d_cv_counts,
                       &e->d_cv_accept, &e->d_cv_tq, &e->d_cv_fail_rows, &e->d_cv_fail_walk, &e->d_run_table})
         b->release();
@@ -2088,6 +2096,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "cv_tree_chunk") == 0 || strcmp(key, "cv_tree_chain_blocks") == 0) {
         (strcmp(key, "cv_tree_chunk") == 0 ? e->cv_tree_chunk : e->cv_tree_chain_blocks) = std::max(1, atoi(value));
+        return VJ_OK;
+    }
+    if (strcmp(key, "tilted_bands") == 0) {
+        e->tilted_bands = atoi(value) != 0;
         return VJ_OK;
     }
     if (strcmp(key, "cv_tiles_tilted") == 0) {   // (part of the plan: cached plans are dropped)

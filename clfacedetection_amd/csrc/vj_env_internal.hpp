@@ -130,6 +130,9 @@ namespace vj {
 // the events that time it.  vj_detect uses the environment's own lane; a vj_stream owns two, so that the upload of
 // batch k+1 can run while the kernels of batch k do.  Integral images, survivor queues and plans are shared: the
 // kernels of successive batches are ordered on the environment's stream.
+// (vj_cv_profile.hip) the tilted integral as three banded prefix sums; diag: n_frames x bands x 2 x (W + H) dwords, col: n_frames x bands x (W + 1)
+int launch_tilted_bands(const TiltedArgs& a, uint32_t* diag, uint32_t* col, void* stream);
+
 struct Lane {
     DevBuf d_gray, d_counts, d_det;
     uint32_t det_cap = 0;
@@ -207,6 +210,8 @@ struct vj_env {
     // image buffers
     vj::DevBuf d_sum, d_sqsum, d_band_sum, d_band_sq, d_band_sqp;
     vj::DevBuf d_tilted;            // tilted integral images (OpenCV profile, cascades with tilted features)
+    vj::DevBuf d_tilt_diag, d_tilt_col;   // ... its band totals (launch_tilted_bands)
+    bool tilted_bands = true;       // the tilted integral as three banded prefix sums (0: the row-by-row recurrence, one workgroup per frame)
     vj::DevBuf d_out;               // scratch for device -> host results (vj_grayscale)
     int slack_w = 0, slack_h = 0, slack_frames = 0;   // layout whose slack rows are known to be zero
     void *slack_sum = nullptr, *slack_sq = nullptr;

@@ -195,7 +195,7 @@ int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
  *   regions / chain    rois_on_device, roi_tiles, group_max
  *   OpenCV profile     cv_tiles, cv_row_blocks, cv_tile_min_windows, cv_tile_min_windows0, cv_tile_ws_max, cv_row_blocks_tree,
  *                      cv_tile_min_windows_tree, cv_tree_chains, cv_tree_chunk, cv_tree_chain_blocks, cv_tail_max, cv_pairs,
- *                      cv_row_band_px, cv_tree2, cv_tiles_tilted,
+ *                      cv_row_band_px, cv_tree2, cv_tiles_tilted, tilted_bands,
  *                      cv_tree_queue_cap (tests)
  *   integral           integral_rows (0 one wave per band of rows, 1 a band's chunks side by side, 2 by call size)
  *   housekeeping       plan_cache_max

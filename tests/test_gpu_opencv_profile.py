@@ -94,20 +94,26 @@ def test_tilted_features(env, oracle, cascades, casc, kind, seed, h, w):
     assert r.windows == st["windows"] and r.stage_entered == st["stage_entered"]
 
 
-def test_tilted_integral_and_gray_image(env, oracle):
+@pytest.mark.parametrize("bands", [1, 0], ids=["banded_prefix_sums", "row_recurrence"])
+def test_tilted_integral_and_gray_image(env, oracle, bands):
     """vj_integral_tilted (cvIntegral's tilted output) and vj_grayscale (clifGrayscale) against the oracle, odd sizes,
-    BGR input and the 32-bit wrap-around included."""
+    BGR input and the 32-bit wrap-around included — with both kernels: the three banded prefix sums (default) and the row-by-row
+    recurrence (`tilted_bands` = 0)."""
     rng = np.random.default_rng(5)
-    for (h, w) in [(1, 1), (3, 5), (64, 300), (251, 333), (480, 640), (1080, 1920)]:
-        img = rng.integers(0, 256, (h, w), dtype=np.uint8)
-        assert np.array_equal(env.integral_tilted(img), oracle.integral_tilted(img)), (h, w)
-        assert np.array_equal(env.grayscale(img), img)
-    white = np.full((3000, 3000), 255, np.uint8)              # tilted sums pass 2^32
-    assert np.array_equal(env.integral_tilted(white), oracle.integral_tilted(white))
-    bgr = rng.integers(0, 256, (120, 200, 3), dtype=np.uint8)
-    g = oracle.bgr2gray(bgr)
-    assert np.array_equal(env.grayscale(bgr), g)
-    assert np.array_equal(env.integral_tilted(bgr), oracle.integral_tilted(g))
+    env.configure("tilted_bands", bands)
+    try:
+        for (h, w) in [(1, 1), (3, 5), (2, 9), (9, 2), (8, 8), (17, 1), (1, 40), (64, 300), (251, 333), (480, 640), (1080, 1920)]:
+            img = rng.integers(0, 256, (h, w), dtype=np.uint8)
+            assert np.array_equal(env.integral_tilted(img), oracle.integral_tilted(img)), (h, w)
+            assert np.array_equal(env.grayscale(img), img)
+        white = np.full((3000, 3000), 255, np.uint8)              # tilted sums pass 2^32
+        assert np.array_equal(env.integral_tilted(white), oracle.integral_tilted(white))
+        bgr = rng.integers(0, 256, (120, 200, 3), dtype=np.uint8)
+        g = oracle.bgr2gray(bgr)
+        assert np.array_equal(env.grayscale(bgr), g)
+        assert np.array_equal(env.integral_tilted(bgr), oracle.integral_tilted(g))
+    finally:
+        env.configure("tilted_bands", 1)
     bgra = rng.integers(0, 256, (77, 131, 4), dtype=np.uint8)
     assert np.array_equal(env.grayscale(bgra[20:60, 10:100]), oracle.bgr2gray(np.ascontiguousarray(bgra[20:60, 10:100])))
 
