@@ -76,7 +76,7 @@ struct TileThresholds {
 };
 
 static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_params& p, Plan* pl, float tile_split,
-                      const TileThresholds& thresholds) {
+                      const TileThresholds& thresholds, bool one_pass = false) {
     pl->tile_split = tile_split;
     if ((int)c.stages.size() > VJ_MAX_STAGES) {
         set_error("cascade has %zu stages; at most %d are supported", c.stages.size(), VJ_MAX_STAGES);
@@ -386,6 +386,11 @@ static int build_plan(vj_env* e, const vj_cascade& c, int W, int H, const vj_par
         }
     }
     pl->pass_bounds = default_pass_bounds(c, pl->prog, e->split_override, e->pass_cut_nodes);
+    // A call of a few frames may run the gather chain in ONE pass (one_pass_max_frames; the first pass runs every stage, thin waves finishing
+    // stump-parallel): one dependent launch fewer — a noise frame at 1080p 1.23 -> 1.15 ms, a 4096 x 4096 one 7.81 -> 7.02 — but frames with
+    // many deep survivors (blocks, drawn faces) lose as much without the queue pass's re-packing (profiles/r04_notes.md #15): off by default
+    // (stump cascades: a tree cascade's thin waves have no stump-parallel form and lose — frontalface_alt2, one 1080p frame, 1.30 -> 1.41 ms)
+    if (one_pass && !pl->general && !pl->trees && e->split_override.empty()) pl->pass_bounds = {0u, (uint32_t)c.stages.size()};
     if (pl->general) {   // positions in StageDev::order: [linear prefix | the rest]
         if (pl->general_prefix) pl->pass_bounds = {0u, pl->general_prefix, pl->n_order};
         else pl->pass_bounds = {0u, pl->n_order};
@@ -815,8 +820,10 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
     const float split = choice.split;
     int small = small_frame_class(e, W, H, n_frames);
     if (small == 0 && choice.thr == 1 && !e->tile_thresholds_set) small = 3;   // the feedback's lower thresholds
+    // (frames of 720p and more: below that the queue pass costs nothing — 640 x 480 0.473 / 0.476 ms with / without it, 320 x 240 the same)
+    const bool one_pass = n_frames <= e->one_pass_max_frames && (uint64_t)W * (uint64_t)H >= 800000ull;
     vj_env::PlanKey key(c->uid, W, H, p.min_w, p.min_h, p.max_w, p.max_h, f2u(p.scale_factor), p.scale_mask[0],
-                        p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64 | VJ_FLAG_TILTED_AS_UPRIGHT)) | ((uint32_t)small << 8), f2u(split));
+                        p.scale_mask[1], (p.flags & (VJ_FLAG_SKIP_LIST | VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64 | VJ_FLAG_TILTED_AS_UPRIGHT)) | ((uint32_t)small << 8) | ((uint32_t)one_pass << 12), f2u(split));
     auto it = e->plans.find(key);
     if (it != e->plans.end()) {
         it->second->last_used = ++e->plan_tick;
@@ -840,7 +847,7 @@ static int get_plan(vj_env* e, const vj_cascade* c, int W, int H, const vj_param
     if (small == 2) th = TileThresholds{64, 64, 8000};
     else if (small == 1) th = TileThresholds{256, 256, 2000};
     else if (small == 3) th = TileThresholds{std::min(384, th.min_windows), std::min(384, th.accept_windows), th.max_dwords_per_window};
-    int rc = build_plan(e, *c, W, H, p, pl.get(), split, th);
+    int rc = build_plan(e, *c, W, H, p, pl.get(), split, th, one_pass);
     if (rc) {
         pl->release_device();
         return rc;
@@ -2096,6 +2103,10 @@ int vj_env_configure(vj_env* e, const char* key, const char* value) {
     }
     if (strcmp(key, "cv_tree_chunk") == 0 || strcmp(key, "cv_tree_chain_blocks") == 0) {
         (strcmp(key, "cv_tree_chunk") == 0 ? e->cv_tree_chunk : e->cv_tree_chain_blocks) = std::max(1, atoi(value));
+        return VJ_OK;
+    }
+    if (strcmp(key, "one_pass_max_frames") == 0) {   // (part of the plan key: nothing to drop)
+        e->one_pass_max_frames = std::max(0, atoi(value));
         return VJ_OK;
     }
     if (strcmp(key, "tilted_bands") == 0) {

@@ -188,6 +188,8 @@ struct vj_env {
     float tile_split = 2.0f;            // batches of >= 32 frames (round 4, band-major queue pass: 64 x 1080p 43.6 / 43.0 / 42.5 / 43.4 / 44.5 ms for 1.5 / 1.75 / 2 / 2.25 / 2.5; round 3: (four gather waves; 64 x 1080p: 46.70 / 46.24 / 45.57 / 45.16 / 45.55 / 46.72 ms for 0.75 / 1 / 1.25 / 1.5 / 1.75 / 2; 32: 23.39 / 23.16 / 22.80 / 22.62 / 22.78 / 23.38)
     float tile_split_mid = 1.75f;       // 8 .. 31 frames (round 4, band-major queue pass: 16 x 1080p 11.53 / 11.36 / 11.13 / 11.01 / 10.89 / 10.90 ms for 0.75 ... 2.0; round 3: (16 x 1080p: 11.81 / 11.67 / 11.47 / 11.52 / 11.86 for 0.75 ... 1.75; 8: 6.03 / 5.95 / 5.97 / 6.24); 5 .. 7 frames (three gather waves): at most 0.5
     float tile_split_small = 0.0f;      // <= 4 frames
+    int one_pass_max_frames = 0;        // calls of at most this many frames (of 720p and more, stump cascades) run the gather chain in ONE pass; 0: never.
+                                        // Content decides which is faster (profiles/r04_notes.md #15: noise -6 %, drawn faces +1-7 %), so it is off by default
     float split_for(int n_frames) const {
         return n_frames <= 4 ? tile_split_small : n_frames < 8 ? std::min(tile_split_mid, 0.5f) : n_frames < 32 ? tile_split_mid : tile_split;
     }

@@ -44,13 +44,13 @@ TUNABLES = [("tile_split", ["0", "0.5", "1.3", "0,1.75,2"]), ("blocks_per_cu", [
             # round 4: band-major queue pass (switched on for any batch size so that the soak's small batches reach it), chain sweeps of the
             # OpenCV profile's stage trees, the balance keyed on the exact frame count
             ("q_band_px", ["128", "0", "32", "700"]), ("q_group_units", ["4", "1", "16"]), ("q_band_min_frames", ["8", "1", "2"]),
-            ("cv_tree_chains", ["1", "0"]), ("cv_tree_chunk", ["64", "256", "100"]), ("cv_tail_max", ["64", "0", "20"]), ("cv_row_band_px", ["128", "0", "37"]), ("cv_tree2", ["1", "0"]), ("cv_tiles_tilted", ["1", "0"]), ("tilted_bands", ["1", "0"]),
+            ("cv_tree_chains", ["1", "0"]), ("cv_tree_chunk", ["64", "256", "100"]), ("cv_tail_max", ["64", "0", "20"]), ("cv_row_band_px", ["128", "0", "37"]), ("cv_tree2", ["1", "0"]), ("cv_tiles_tilted", ["1", "0"]), ("tilted_bands", ["1", "0"]), ("one_pass_max_frames", ["0", "4", "1"]),
             ("cv_tree_chain_blocks", ["2", "1"]), ("cv_tile_min_windows_tree", ["256", "64", "2048"]), ("balance_exact", ["0", "1"])]
 DEFAULTS = {"tile_split": "0,1.75,2", "blocks_per_cu": "8", "gather_pairs": "-1", "sp_tail_max": "48", "thin_pass_spread": "1", "tree_split_queues": "1",
             "concurrent": "1", "tile_classes_kb": "-2,-1,0", "grid_block_w": "32", "max_subbatch": "0", "group_max": "2048", "rois_on_device": "1", "roi_tiles": "512", "integral_rows": "2", "wide_tail": "-1", "min_chunk": "32",
             "q_slices": "-1", "gather_waves": "-1", "cv_tiles": "1", "cv_tile_ws_max": "512", "cv_row_blocks": "-1", "cv_tile_min_windows": "-1", "cv_tile_min_windows0": "2048",
             "auto_balance": "1", "q_band_px": "128", "q_group_units": "4", "q_band_min_frames": "8", "cv_tree_chains": "1", "cv_tree_chunk": "64",
-            "cv_tail_max": "64", "cv_row_band_px": "128", "cv_tree2": "1", "cv_tiles_tilted": "1", "tilted_bands": "1", "cv_pairs": "1", "cv_tree_chain_blocks": "2", "cv_tile_min_windows_tree": "256", "balance_exact": "0"}
+            "cv_tail_max": "64", "cv_row_band_px": "128", "cv_tree2": "1", "cv_tiles_tilted": "1", "tilted_bands": "1", "one_pass_max_frames": "0", "cv_pairs": "1", "cv_tree_chain_blocks": "2", "cv_tile_min_windows_tree": "256", "balance_exact": "0"}
 
 
 def rows(r):
