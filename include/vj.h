@@ -197,6 +197,7 @@ int  vj_env_device_name(const vj_env* e, char* buf, size_t cap);
  *                      cv_tile_min_windows_tree, cv_tree_chains, cv_tree_chunk, cv_tree_chain_blocks, cv_tail_max, cv_pairs,
  *                      cv_row_band_px, cv_tree2, cv_tiles_tilted, tilted_bands,
  *                      cv_tree_queue_cap (tests)
+ *   single frames      one_pass_max_frames (the gather chain in one pass for calls of few large frames; 0 = off)
  *   integral           integral_rows (0 one wave per band of rows, 1 a band's chunks side by side, 2 by call size)
  *   housekeeping       plan_cache_max
  * Unknown keys return VJ_ERR_ARG.                                               */
