@@ -87,6 +87,14 @@ FULLSIZE = {
                ("cv_alt_tree_faces_1080", "frontalface_alt_tree", "faces", 6, 1080, 1920),
                ("cv_alt2_faces_1080", "frontalface_alt2", "faces", 7, 1080, 1920),
                ("cv_fullbody_smooth_1080", "fullbody", "smooth", 8, 1080, 1920)],
+    # (id, cascade, generator, seed, height, width): cascades the configs do not name, at 1080p in BOTH profiles (the clod profile reads
+    # tilted rectangles as upright ones, like the reference)
+    "shipped": [("s_upperbody_blocks_1080", "upperbody", "blocks", 11, 1080, 1920),
+                ("s_mcs_mouth_faces_1080", "mcs_mouth", "faces", 12, 1080, 1920),
+                ("s_eyepair_small_noise_1080", "mcs_eyepair_small", "noise", 13, 1080, 1920),
+                ("s_lowerbody_smooth_1080", "lowerbody", "smooth", 14, 1080, 1920),
+                ("s_righteye_2splits_faces_1080", "righteye_2splits", "faces", 15, 1080, 1920),
+                ("s_profileface_faces_1080", "profileface", "faces", 16, 1080, 1920)],
     # (id, cascade, generator, seed, height, width, oracle mode): the CPU variants' window sets at 1080p
     "modes": [(f"m{mode}_{kind}_1080", "frontalface_alt", kind, seed, 1080, 1920, mode)
               for mode in (2, 3, 4, 5) for kind, seed in (("noise", 1), ("smooth", 2), ("faces", 4))],

@@ -124,6 +124,15 @@ def test_fullsize_fixture_sample(oracle, cascades):
     r, st = oracle.detect_opencvlike(a, make_frame(e["generator"], e["seed"], e["height"], e["width"], oracle))
     r = r[np.lexsort((r["x"], r["y"], r["scale_idx"]))]
     assert (len(r), rows_sha(r)) == (e["n"], e["sha"]) and st["windows"] == e["windows"]
+    assert [[e[k] for k in ("id", "cascade", "generator", "seed", "height", "width")] for e in FULL["shipped"]] == [list(t) for t in FULLSIZE["shipped"]]
+    e = next(e for e in FULL["shipped"] if e["id"] == "s_lowerbody_smooth_1080")      # 19 x 23 window, tilted nodes read as upright in the clod path
+    _, al = cascades(e["cascade"])
+    img = make_frame(e["generator"], e["seed"], e["height"], e["width"], oracle)
+    r, st = oracle.detect(al, img)
+    assert (len(r), rows_sha(r)) == (e["clod"]["n"], e["clod"]["sha"]) and st["stage_entered"] == e["clod"]["stage_entered"]
+    r, st = oracle.detect_opencvlike(al, img)
+    r = r[np.lexsort((r["x"], r["y"], r["scale_idx"]))]
+    assert (len(r), rows_sha(r)) == (e["opencv"]["n"], e["opencv"]["sha"]) and st["windows"] == e["opencv"]["windows"]
     g = FULL["config5_grouped"]
     _, a1 = cascades(g["cascade"])
     _, a2 = cascades(g["second"])

@@ -10,7 +10,7 @@ import numpy as np
 import pytest
 
 from cases import FULLSIZE, make_frame, rows_sha
-from clfacedetection_amd import (VJ_FLAG_COUNTERS, VJ_FLAG_GRID_F64, VJ_FLAG_SKIP_LIST, VJ_FLAG_SKIP_ROW, DeviceFrames,
+from clfacedetection_amd import (VJ_FLAG_COUNTERS, VJ_FLAG_GRID_F64, VJ_FLAG_SKIP_LIST, VJ_FLAG_SKIP_ROW, VJ_FLAG_TILTED_AS_UPRIGHT, DeviceFrames,
                                  default_params, synth)
 
 pytestmark = pytest.mark.gpu
@@ -226,6 +226,31 @@ def test_opencv_profile_at_1080p(env, oracle, cascades, g):
         qf = rb.rects[rb.rects["frame"] == f]
         qf = qf[np.lexsort((qf["x"], qf["y"], qf["scale_idx"]))]
         assert (len(qf), rows_sha(qf)) == (g["n"], g["sha"])
+
+
+@pytest.mark.parametrize("g", GOLD.get("shipped", []), ids=lambda d: d["id"])
+def test_shipped_cascades_at_1080p_in_both_profiles(env, oracle, cascades, g):
+    """Cascades the configs do not name — non-square base windows, tilted features, two-node trees with tilted nodes — on 1080p frames:
+    the clod profile (tilted rectangles read as upright ones, like the reference) and the OpenCV profile (tilted features on LDS tiles)
+    against the oracle's results frozen in tests/golden/fullsize.json; single frames counted, and inside a batch."""
+    assert [g[k] for k in ("id", "cascade", "generator", "seed", "height", "width")] in [list(t) for t in FULLSIZE["shipped"]]
+    c, _ = cascades(g["cascade"])
+    img = make_frame(g["generator"], g["seed"], g["height"], g["width"], oracle)
+    p = default_params(flags=VJ_FLAG_COUNTERS | VJ_FLAG_TILTED_AS_UPRIGHT)
+    r = env.detect(c, img, p)
+    gc = g["clod"]
+    assert (len(r.rects), rows_sha(r.rects)) == (gc["n"], gc["sha"]) and r.windows == gc["windows"] and r.stage_entered == gc["stage_entered"]
+    rb = env.detect(c, np.stack([img] * 9), default_params(flags=VJ_FLAG_TILTED_AS_UPRIGHT))      # (9 frames: the band-major queue pass)
+    assert per_frame(rb.rects, 9) == [(gc["n"], gc["sha"])] * 9
+    go = g["opencv"]
+    ro = env.detect_opencv(c, img, flags=VJ_FLAG_COUNTERS)
+    q = ro.rects[np.lexsort((ro.rects["x"], ro.rects["y"], ro.rects["scale_idx"]))]
+    assert (len(q), rows_sha(q)) == (go["n"], go["sha"]) and ro.windows == go["windows"] and ro.stage_entered == go["stage_entered"]
+    rob = env.detect_opencv(c, np.stack([img] * 6))
+    for f in range(6):
+        qf = rob.rects[rob.rects["frame"] == f]
+        qf = qf[np.lexsort((qf["x"], qf["y"], qf["scale_idx"]))]
+        assert (len(qf), rows_sha(qf)) == (go["n"], go["sha"])
 
 
 MODE_FLAGS = {2: VJ_FLAG_SKIP_LIST, 3: VJ_FLAG_SKIP_ROW, 4: VJ_FLAG_SKIP_ROW | VJ_FLAG_GRID_F64, 5: VJ_FLAG_SKIP_LIST | VJ_FLAG_GRID_F64}

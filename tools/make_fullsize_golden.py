@@ -102,6 +102,17 @@ def w_opencv(case):
             "sha": rows_sha(r), "windows": st["windows"], "stage_entered": st["stage_entered"]}
 
 
+def w_shipped(case):
+    cid, cname, gen, seed, h, w = case
+    img = make_frame(gen, seed, h, w, orc())
+    r, st = orc().detect(casc(cname), img)
+    rc, sc = orc().detect_opencvlike(casc(cname), img)
+    rc = rc[np.lexsort((rc["x"], rc["y"], rc["scale_idx"]))]
+    return {"id": cid, "cascade": cname, "generator": gen, "seed": seed, "height": h, "width": w,
+            "clod": {"n": len(r), "sha": rows_sha(r), "windows": st["windows"], "stage_entered": st["stage_entered"]},
+            "opencv": {"n": len(rc), "sha": rows_sha(rc), "windows": sc["windows"], "stage_entered": sc["stage_entered"]}}
+
+
 def w_mode(case):
     cid, cname, gen, seed, h, w, mode = case
     img = make_frame(gen, seed, h, w, orc())
@@ -157,12 +168,16 @@ def sec_opencv(pool):
     return pool.map(w_opencv, FULLSIZE["opencv"], chunksize=1)
 
 
+def sec_shipped(pool):
+    return pool.map(w_shipped, FULLSIZE["shipped"], chunksize=1)
+
+
 def sec_modes(pool):
     return pool.map(w_mode, FULLSIZE["modes"], chunksize=1)
 
 
 SECTIONS = {"config3": sec_config3, "modes": sec_modes, "config4": sec_config4, "config5_raw": sec_config5_raw,
-            "config5_grouped": sec_config5_grouped, "opencv": sec_opencv}
+            "config5_grouped": sec_config5_grouped, "opencv": sec_opencv, "shipped": sec_shipped}
 
 if __name__ == "__main__":
     want = sys.argv[1:] or list(SECTIONS)
